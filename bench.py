@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the reach+distance hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the fused reach+distance kernel (lrm_reach_dist_bits_dev: reach mask
+as bytes and ballot bit words + 3-component distance field) over one synthetic cloud that is
+already resident in HBM as SoA float32.  At N=1 the cloud is BASELINE.json config 2: 1e7
+uniform-random targets in [-200,700]x[-500,500]x[-500,300] mm (seed 42), M2 leg, identity
+orientation.  For N>1 (one process per GPU, torch.distributed over RCCL) every rank holds its
+own 1e7-point shard (weak scaling) and each step ends with the RCCL all-gather of the
+bit-packed reach mask, issued on a side stream so that it overlaps the next step's kernel.
+
+value = leg-target evaluations per second over the whole job (all ranks), where one
+evaluation = reachability AND distance vector for one (leg, target) pair.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_PER_EVAL = {"reach": 13, "dist": 24, "reach_dist": 25}
+
+
+def make_cloud(n, seed):
+    rng = np.random.default_rng(seed)
+    lo = np.array([-200, -500, -500], np.float32)
+    hi = np.array([700, 500, 300], np.float32)
+    out = np.empty((3, n), np.float32)
+    chunk = 2_000_000
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        out[:, s:e] = (rng.random((e - s, 3), dtype=np.float32) * (hi - lo) + lo).T
+    return out
+
+
+def cpu_baseline(sample_points, leg):
+    """Reference host path (oracle/_ref, kind "reference") or the C oracle (kind "port") timed
+    on this box's cores: reach loop + distance loop over a bounded sample of the same cloud."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import orc
+    if orc.ref_available():
+        impl, kind = orc.Ref(), "reference"
+    else:
+        impl, kind = orc.Oracle(), "port"
+    pts = np.ascontiguousarray(sample_points.T)  # AoS, as the reference's Array<float3>
+    n = len(pts)
+    # one thread: the reference's apply_reach_cpu/apply_dist_cpu are single-threaded
+    n1 = min(n, 4_000_000)
+    t0 = time.perf_counter()
+    impl.reach(pts[:n1], leg)
+    impl.dist(pts[:n1], leg)
+    single = n1 / (time.perf_counter() - t0)
+    cores = min(os.cpu_count() or 1, 16)
+    parts = np.array_split(np.arange(n), cores)
+
+    def work(idx):
+        sl = pts[idx[0]:idx[-1] + 1]
+        impl.reach(sl, leg)
+        impl.dist(sl, leg)
+
+    with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL during the C loops
+        t0 = time.perf_counter()
+        list(ex.map(work, parts))
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "leg-target evaluations/s (reach+dist)", "cores": cores, "kind": kind,
+            "sample": f"first {n} points of the same cloud, reach loop + distance loop, {cores} threads "
+                      f"(static split); single thread on {n1} points: {single:.3e}/s",
+            "single_thread_value": single}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=10_000_000, help="targets per GPU")
+    ap.add_argument("--mode", choices=["strict", "fast"], default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import lrm_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.mode:
+        lrm_amd.set_mode(lrm_amd.MODE_FAST if args.mode == "fast" else lrm_amd.MODE_STRICT)
+    mode = "fast" if lrm_amd.get_mode() == lrm_amd.MODE_FAST else "strict"
+
+    n = args.points
+    leg = lrm_amd.get_M2_leg(0.0)
+    host = make_cloud(n, seed=42 + rank)
+    cloud = torch.from_numpy(host).cuda()
+    x, y, z = cloud[0], cloud[1], cloud[2]
+    nwords = (n + 63) // 64
+    mask = torch.empty(n, dtype=torch.uint8, device="cuda")
+    field = torch.empty((3, n), dtype=torch.float32, device="cuda")
+    bits = [torch.empty(nwords, dtype=torch.int64, device="cuda") for _ in range(2)]
+    gathered = [torch.empty(nwords * world, dtype=torch.int64, device="cuda") for _ in range(2)] if world > 1 else None
+    comm_stream = torch.cuda.Stream() if world > 1 else None
+    gather_done = [None, None]
+
+    def step(k, ev=None):
+        b = k & 1
+        if world > 1 and gather_done[b] is not None:
+            torch.cuda.current_stream().wait_event(gather_done[b])  # bits[b] is free again
+        if ev:
+            ev[0].record()
+        lrm_amd.device.reach_dist(x, y, z, leg, None, mask=mask, out=field, bits=bits[b])
+        if ev:
+            ev[1].record()
+        if world > 1:
+            ready = torch.cuda.Event()
+            ready.record()
+            comm_stream.wait_event(ready)
+            with torch.cuda.stream(comm_stream):
+                dist.all_gather_into_tensor(gathered[b], bits[b])
+                gather_done[b] = torch.cuda.Event()
+                gather_done[b].record()
+
+    def full_sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    full_sync()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, events[k])
+    full_sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    # secondary figures (not part of the timed region): reach-only and distance-only kernels
+    def time_kernel(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    extra = {}
+    if rank == 0:
+        ms_reach = time_kernel(lambda: lrm_amd.device.reach(x, y, z, leg, out=mask, bits=bits[0]))
+        valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ms_dist = time_kernel(lambda: lrm_amd.device.dist(x, y, z, leg, out=field, valid=valid))
+        extra = {
+            "reach_only": {"evals_per_s": n / (ms_reach * 1e-3), "ms": ms_reach,
+                           "hbm_GBs": BYTES_PER_EVAL["reach"] * n / (ms_reach * 1e-3) / 1e9},
+            "dist_only": {"evals_per_s": n / (ms_dist * 1e-3), "ms": ms_dist,
+                          "hbm_GBs": BYTES_PER_EVAL["dist"] * n / (ms_dist * 1e-3) / 1e9},
+        }
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        total_evals = float(n) * world * args.steps
+        achieved = BYTES_PER_EVAL["reach_dist"] * n / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "leg-target evaluations/sec (reach+dist)",
+            "value": total_evals / elapsed,
+            "unit": "evaluations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE config 2: single M2 leg, reach+distance on {n} uniform-random 3-D targets "
+                            f"per GPU (seed 42+rank), identity orientation, SoA resident in HBM",
+                "points_per_gpu": n, "mode": mode,
+                "exchange": "none" if world == 1 else "RCCL all-gather of the bit-packed reach mask per step, "
+                                                         "overlapped on a side stream",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "dist_soa_kernel<2> (fused reach+distance)", "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_eval": BYTES_PER_EVAL["reach_dist"],
+            },
+            "kernels": extra,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(host, leg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/*
+ * lrm.h -- C ABI of liblrm.so: the MI355X (gfx950) implementation of the batched 3-DoF
+ * (yaw-pitch-pitch) leg reachability / distance path and of the body x target
+ * positionability aggregation.
+ *
+ * Every entry point names the interface of the reference (2lian/Legged-Robot-Movability-Cuda,
+ * paths relative to its root) that it replaces.  Plain pointers and sizes only.
+ * All functions returning `int` return 0 on success and a negative LRM_E* code on failure;
+ * lrm_last_error() then holds a message.  Nothing here ever computes a GPU entry point on
+ * the CPU: without a usable HIP device the *_dev / host-buffer GPU calls fail with LRM_ENODEV.
+ *
+ * Units: millimetres and radians, float32 arithmetic (reference convention).
+ * Quaternions are float[4] = {x,y,z,w} in the reference's own (inconsistent) convention:
+ * qtRotate/qtInvert read [0] as the scalar part (identity = {1,0,0,0}, settings.h:51).
+ */
+#ifndef LRM_H
+#define LRM_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRM_OK 0
+#define LRM_EINVAL (-1) /* bad argument (null pointer, length mismatch, too many legs...) */
+#define LRM_ENODEV (-2) /* no HIP device / HIP runtime error                               */
+#define LRM_ENOMEM (-3) /* device or host allocation failed                               */
+
+/* Arithmetic mode of the GPU kernels.
+ * LRM_MODE_STRICT: reference operation order, no FMA contraction, glibc-exact atan2f/sincosf:
+ *                  bit-identical to the reference's host path (reachability_kernel_cpu /
+ *                  distance_kernel_cpu, one_leg_global.cu:132-147).
+ * LRM_MODE_FAST:   filtered evaluation: hoisted/algebraically simplified predicates with
+ *                  conservative error bands; any point whose decision falls inside a band is
+ *                  re-evaluated by the strict code, so the mask stays bit-identical. */
+#define LRM_MODE_STRICT 0
+#define LRM_MODE_FAST 1
+
+/* LegDimensions, HeaderCPP.h:19-52: 14 x f32 = 56 bytes, this field order. */
+typedef struct LrmLegDimensions {
+    float body_angle;
+    float body;
+    float coxa_pitch;
+    float coxa_length;
+    float tibia_length;
+    float femur_length;
+    float tibia_absolute_pos;
+    float tibia_absolute_neg;
+    float max_angle_coxa;
+    float min_angle_coxa;
+    float max_angle_tibia;
+    float min_angle_tibia;
+    float max_angle_femur;
+    float min_angle_femur;
+} LrmLegDimensions;
+
+/* ---- library state ------------------------------------------------------------------ */
+const char* lrm_version(void);
+const char* lrm_last_error(void);
+int lrm_device_count(void);          /* number of HIP devices, 0 if none (never fails)      */
+int lrm_set_device(int ordinal);     /* cudaSetDevice analogue; the reference uses device 0 */
+int lrm_set_mode(int mode);          /* LRM_MODE_*; process-wide default for all launches   */
+int lrm_get_mode(void);
+
+/* ---- leg factories: static_variables.cpp:6-93 ---------------------------------------- */
+void lrm_leg_factory(float azimut, float body2coxa, float coxa_pitch_deg, float coxa2tibia,
+                     float tibia2femur, float femur2tip, float coxa_angle_deg,
+                     float femur_angle_deg, float tibia_angle_deg, float tib_abs_pos,
+                     float tib_abs_neg, LrmLegDimensions* out);
+void lrm_get_M2_leg(float azimut, LrmLegDimensions* out);      /* static_variables.cpp:69-93 */
+void lrm_get_moonbot_leg(float azimut, LrmLegDimensions* out); /* static_variables.cpp:44-67 */
+
+/* rotate_leg_data, one_leg_global.cu:48-60 (host helper; also several_leg.cu:743-760) */
+void lrm_rotate_leg_data(const float quat[4], const LrmLegDimensions* leg, LrmLegDimensions* out);
+
+/* ---- host-buffer drop-ins ------------------------------------------------------------
+ * Replace apply_kernel<float3,LegDimensions,bool|float3> (cross_compiled.cu:33-79) for the
+ * kernels reachability_global_kernel / distance_global_kernel (one_leg_global.cu:149-166):
+ * device buffers are allocated and freed inside the call, input is copied H2D, a warm-up
+ * launch runs, the kernel alone is timed with events, results are copied D2H.
+ * xyz is AoS float3 (12-byte stride), mask is one byte per point (C++ bool), *ms receives
+ * the kernel-only milliseconds.  `quat` = NULL means the reference's quatTest {1,0,0,0}. */
+int lrm_reach(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+              uint8_t* mask_out, float* ms);
+int lrm_dist(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+             float* dxyz_aos_out, uint8_t* valid_out /* may be NULL */, float* ms);
+/* one launch producing both outputs (mask is reachability_global's, not distance's bool) */
+int lrm_reach_dist(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+                   uint8_t* mask_out, float* dxyz_aos_out, float* ms);
+
+/* ---- CPU path: apply_reach_cpu / apply_dist_cpu, cross_compiled.cu:163-181 -------------
+ * Single-threaded host loops over the same per-point code the kernels run (the reference
+ * compiles one `__host__ __device__` source twice in the same way).  These are explicit CPU
+ * entry points of the reference API, never a fallback for the GPU ones. */
+int lrm_reach_cpu(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+                  uint8_t* mask_out, double* ms);
+int lrm_dist_cpu(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+                 float* dxyz_aos_out, uint8_t* valid_out /* may be NULL */, double* ms);
+
+/* ---- device-resident entry points (no allocation, no copy, no sync) --------------------
+ * Pointers are device pointers; coordinates are SoA (one f32 array per component: the same
+ * layout the reference keeps on disk, several_leg.cpp:126-131).  `stream` is a hipStream_t
+ * (NULL = default stream).  `n` need not be a multiple of anything; arrays must be 16-byte
+ * aligned (hipMalloc / torch allocations are).  Launch only: the caller synchronises. */
+int lrm_reach_dev(const float* x, const float* y, const float* z, size_t n,
+                  const LrmLegDimensions* leg, const float* quat, uint8_t* mask, void* stream);
+/* as lrm_reach_dev, plus a wave-ballot bit mask: bit (i & 63) of bits[i >> 6]
+ * (ceil(n/64) words; either output may be NULL) */
+int lrm_reach_bits_dev(const float* x, const float* y, const float* z, size_t n,
+                       const LrmLegDimensions* leg, const float* quat, uint8_t* mask,
+                       uint64_t* bits, void* stream);
+int lrm_dist_dev(const float* x, const float* y, const float* z, size_t n,
+                 const LrmLegDimensions* leg, const float* quat, float* dx, float* dy, float* dz,
+                 uint8_t* valid /* may be NULL */, void* stream);
+int lrm_reach_dist_dev(const float* x, const float* y, const float* z, size_t n,
+                       const LrmLegDimensions* leg, const float* quat, uint8_t* mask, float* dx,
+                       float* dy, float* dz, void* stream);
+/* as lrm_reach_dist_dev, plus the wave-ballot bit mask of the reach mask (the shard payload
+ * of the multi-GPU gather); either mask output may be NULL */
+int lrm_reach_dist_bits_dev(const float* x, const float* y, const float* z, size_t n,
+                            const LrmLegDimensions* leg, const float* quat, uint8_t* mask,
+                            uint64_t* bits, float* dx, float* dy, float* dz, void* stream);
+/* AoS device variants (what apply_kernel launches on its device copies) */
+int lrm_reach_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat,
+                      uint8_t* mask, void* stream);
+int lrm_dist_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat,
+                     float* dxyz, uint8_t* valid /* may be NULL */, void* stream);
+
+/* ---- body x target aggregation ---------------------------------------------------------
+ * Replaces reach_mem_kernel + launch_opti_mem_reach_kernel (several_leg.cu:92-192) for all
+ * legs in ONE launch: out[l*nb + b] = 1 iff some target t satisfies
+ * reachable_rotate_leg(t, body b, quat, legs[l]) (several_leg.cu:48-67); otherwise 0 (the
+ * whole output is written).  `legs` are used as given (several_leg.cu:743-760 rotates the
+ * limits on the host before the launch: use lrm_rotate_leg_data for that).
+ * If all_legs_out != NULL it receives the AND over legs per body (agregateReachability,
+ * several_leg.cu:681-697, generalised from 4 to nlegs legs). nlegs <= LRM_MAX_LEGS. */
+#define LRM_MAX_LEGS 8
+int lrm_reach_any_dev(const float* bx, const float* by, const float* bz, size_t nb,
+                      const float* tx, const float* ty, const float* tz, size_t nt,
+                      const LrmLegDimensions* legs, size_t nlegs, const float* quat,
+                      uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream);
+/* host-buffer form (AoS in, as robot_full_struct's Array<float3> arguments,
+ * several_leg.cu:796-808); quats is nquat x 4; body_mask_out[b] = 1 iff for SOME
+ * orientation EVERY leg (limits rotated per orientation) has a reachable target. */
+int lrm_positionability(const float* bodies_aos, size_t nb, const float* targets_aos, size_t nt,
+                        const LrmLegDimensions* legs, size_t nlegs, const float* quats,
+                        size_t nquat, uint8_t* body_mask_out, float* ms);
+
+/* in_sphere / in_cylinder any-reductions: launch_optimized_mem_in_sphere /
+ * launch_optimized_mem_in_cylinder (collision.cu:68-98, :148-168):
+ * out[c] = 1 iff some target lies in the sphere / cylinder centred on centre c. */
+int lrm_any_in_sphere_dev(const float* cx, const float* cy, const float* cz, size_t nc,
+                          const float* tx, const float* ty, const float* tz, size_t nt,
+                          float radius, uint8_t* out, void* stream);
+int lrm_any_in_cylinder_dev(const float* cx, const float* cy, const float* cz, size_t nc,
+                            const float* tx, const float* ty, const float* tz, size_t nt,
+                            float radius, float plus_z, float minus_z, uint8_t* out, void* stream);
+
+/* ---- diagnostics -------------------------------------------------------------------------
+ * The glibc-exact atan2f / sincosf of the strict kernels (csrc/lrm_exact_math.h) applied to
+ * arrays: at2[i] = atan2f(a[i], b[i]); (sn[i], cs[i]) = sincosf(a[i]).  Host build and device
+ * build; tests compare both with the platform libm. */
+int lrm_dbg_exact_math_host(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs);
+int lrm_dbg_exact_math_dev(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRM_H */

@@ -1,0 +1,12 @@
+"""MI355X-native reach / distance / positionability path (drop-in for the hot path of
+2lian/Legged-Robot-Movability-Cuda).  The product is csrc/ -> liblrm.so (HIP kernels + the
+C ABI of include/lrm.h); this package is the Python binding used by tests and bench.py.
+The C++ mirror of the reference's host interface is include/lrm_compat.hpp.
+"""
+from ._capi import (  # noqa: F401
+    LIB_PATH, LrmError, MODE_FAST, MODE_STRICT, build, lib, load, leg_factory, get_M2_leg,
+    get_moonbot_leg, rotate_leg_data, apply_reach, apply_dist, apply_reach_dist,
+    apply_reach_cpu, apply_dist_cpu, positionability, set_mode, get_mode, device_count,
+    exported_symbols, declared_symbols,
+)
+from . import device  # noqa: F401

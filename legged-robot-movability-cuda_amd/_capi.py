@@ -1,0 +1,212 @@
+"""ctypes binding of liblrm.so (include/lrm.h).  No compute happens in Python, and there
+is no fallback: if the shared library is missing, load() raises."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblrm.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lrm.h")
+MODE_STRICT, MODE_FAST = 0, 1
+_lib = None
+
+
+class LrmError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/ into liblrm.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], check=True,
+                   stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def declared_symbols():
+    """Every function name declared in include/lrm.h."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lrm_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported_symbols():
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB_PATH], check=True,
+                         capture_output=True, text=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LrmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, fp = C.c_void_p, C.c_size_t, C.c_float
+    L.lrm_version.restype = C.c_char_p
+    L.lrm_last_error.restype = C.c_char_p
+    sig = {
+        "lrm_device_count": [], "lrm_set_device": [C.c_int], "lrm_set_mode": [C.c_int], "lrm_get_mode": [],
+        "lrm_reach": [vp, sz, vp, vp, vp, vp],
+        "lrm_dist": [vp, sz, vp, vp, vp, vp, vp],
+        "lrm_reach_dist": [vp, sz, vp, vp, vp, vp, vp],
+        "lrm_reach_cpu": [vp, sz, vp, vp, vp, vp],
+        "lrm_dist_cpu": [vp, sz, vp, vp, vp, vp, vp],
+        "lrm_reach_dev": [vp, vp, vp, sz, vp, vp, vp, vp],
+        "lrm_reach_bits_dev": [vp, vp, vp, sz, vp, vp, vp, vp, vp],
+        "lrm_dist_dev": [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp],
+        "lrm_reach_dist_dev": [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp],
+        "lrm_reach_dist_bits_dev": [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp],
+        "lrm_reach_aos_dev": [vp, sz, vp, vp, vp, vp],
+        "lrm_dist_aos_dev": [vp, sz, vp, vp, vp, vp, vp],
+        "lrm_reach_any_dev": [vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp],
+        "lrm_positionability": [vp, sz, vp, sz, vp, sz, vp, sz, vp, vp],
+        "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
+        "lrm_dbg_exact_math_dev": [vp, vp, sz, vp, vp, vp, vp],
+        "lrm_any_in_sphere_dev": [vp, vp, vp, sz, vp, vp, vp, sz, fp, vp, vp],
+        "lrm_any_in_cylinder_dev": [vp, vp, vp, sz, vp, vp, vp, sz, fp, fp, fp, vp, vp],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    L.lrm_leg_factory.argtypes = [fp] * 11 + [vp]
+    L.lrm_leg_factory.restype = None
+    for name in ("lrm_get_M2_leg", "lrm_get_moonbot_leg"):
+        getattr(L, name).argtypes = [fp, vp]
+        getattr(L, name).restype = None
+    L.lrm_rotate_leg_data.argtypes = [vp, vp, vp]
+    L.lrm_rotate_leg_data.restype = None
+    _lib = L
+    return L
+
+
+def lib():
+    return load()
+
+
+def check(rc):
+    if rc != 0:
+        raise LrmError(f"liblrm error {rc}: {load().lrm_last_error().decode()}")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+def _quat(q):
+    return None if q is None else _f32(q, (4,))
+
+
+def device_count():
+    return load().lrm_device_count()
+
+
+def set_mode(mode):
+    check(load().lrm_set_mode(mode))
+
+
+def get_mode():
+    return load().lrm_get_mode()
+
+
+# ---- leg factories (static_variables.cpp:6-93) -------------------------------------------
+def leg_factory(azimut, body2coxa, coxa_pitch_deg, coxa2tibia, tibia2femur, femur2tip,
+                coxa_angle_deg, femur_angle_deg, tibia_angle_deg, tib_abs_pos, tib_abs_neg):
+    out = np.zeros(14, np.float32)
+    load().lrm_leg_factory(azimut, body2coxa, coxa_pitch_deg, coxa2tibia, tibia2femur, femur2tip,
+                           coxa_angle_deg, femur_angle_deg, tibia_angle_deg, tib_abs_pos, tib_abs_neg,
+                           _ptr(out))
+    return out
+
+
+def get_M2_leg(azimut=0.0):
+    out = np.zeros(14, np.float32)
+    load().lrm_get_M2_leg(azimut, _ptr(out))
+    return out
+
+
+def get_moonbot_leg(azimut=0.0):
+    out = np.zeros(14, np.float32)
+    load().lrm_get_moonbot_leg(azimut, _ptr(out))
+    return out
+
+
+def rotate_leg_data(quat, leg):
+    out = np.zeros(14, np.float32)
+    load().lrm_rotate_leg_data(_ptr(_f32(quat, (4,))), _ptr(_f32(leg, (14,))), _ptr(out))
+    return out
+
+
+# ---- host-buffer drop-ins (apply_kernel, cross_compiled.cu:33-79) -------------------------
+def apply_reach(xyz, leg, quat=None):
+    """-> (mask uint8[n], kernel milliseconds); GPU."""
+    xyz = _f32(xyz, (-1, 3))
+    mask = np.zeros(len(xyz), np.uint8)
+    ms = C.c_float(0)
+    check(load().lrm_reach(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask),
+                           C.addressof(ms)))
+    return mask, ms.value
+
+
+def apply_dist(xyz, leg, quat=None):
+    """-> (distance float32[n,3], validity uint8[n], kernel milliseconds); GPU."""
+    xyz = _f32(xyz, (-1, 3))
+    d = np.zeros_like(xyz)
+    v = np.zeros(len(xyz), np.uint8)
+    ms = C.c_float(0)
+    check(load().lrm_dist(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(d), _ptr(v),
+                          C.addressof(ms)))
+    return d, v, ms.value
+
+
+def apply_reach_dist(xyz, leg, quat=None):
+    xyz = _f32(xyz, (-1, 3))
+    d = np.zeros_like(xyz)
+    m = np.zeros(len(xyz), np.uint8)
+    ms = C.c_float(0)
+    check(load().lrm_reach_dist(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(m), _ptr(d),
+                                C.addressof(ms)))
+    return m, d, ms.value
+
+
+# ---- CPU entry points (apply_reach_cpu / apply_dist_cpu, cross_compiled.cu:163-181) --------
+def apply_reach_cpu(xyz, leg, quat=None):
+    xyz = _f32(xyz, (-1, 3))
+    mask = np.zeros(len(xyz), np.uint8)
+    ms = C.c_double(0)
+    check(load().lrm_reach_cpu(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask),
+                               C.addressof(ms)))
+    return mask, ms.value
+
+
+def apply_dist_cpu(xyz, leg, quat=None):
+    xyz = _f32(xyz, (-1, 3))
+    d = np.zeros_like(xyz)
+    v = np.zeros(len(xyz), np.uint8)
+    ms = C.c_double(0)
+    check(load().lrm_dist_cpu(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(d), _ptr(v),
+                              C.addressof(ms)))
+    return d, v, ms.value
+
+
+def positionability(bodies, targets, legs, quats):
+    """robot_full_struct's result as a mask (several_leg.cu:796-877) -> (uint8[nb], ms); GPU."""
+    bodies = _f32(bodies, (-1, 3))
+    targets = _f32(targets, (-1, 3))
+    legs = _f32(legs).reshape(-1, 14)
+    quats = _f32(quats).reshape(-1, 4)
+    out = np.zeros(len(bodies), np.uint8)
+    ms = C.c_float(0)
+    check(load().lrm_positionability(_ptr(bodies), len(bodies), _ptr(targets), len(targets), _ptr(legs),
+                                     len(legs), _ptr(quats), len(quats), _ptr(out), C.addressof(ms)))
+    return out, ms.value

@@ -1,0 +1,373 @@
+// lrm_capi.cpp -- the extern "C" boundary of liblrm.so (include/lrm.h).
+#include "../../include/lrm.h"
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "lrm_compile.h"
+#include "lrm_launch.h"
+#include "lrm_point.h"
+
+namespace {
+
+thread_local std::string g_err;
+int g_mode = LRM_MODE_STRICT;
+const float kQuatTest[4] = {1.f, 0.f, 0.f, 0.f}; // settings.h:51
+
+int fail(int code, const char* what) {
+    g_err = what;
+    return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return (e == hipErrorOutOfMemory) ? LRM_ENOMEM : LRM_ENODEV;
+}
+#define HIP_TRY(expr, where)                              \
+    do {                                                  \
+        hipError_t e_ = (expr);                           \
+        if (e_ != hipSuccess) return hip_fail(e_, where); \
+    } while (0)
+
+const float* quat_or_default(const float* q) { return q ? q : kQuatTest; }
+
+// RAII device buffer for the host-buffer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+struct Events {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+// host-buffer skeleton of apply_kernel (cross_compiled.cu:33-79)
+// op: 0 reach, 1 dist, 2 reach+dist
+int host_apply(int op, const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat,
+               uint8_t* mask_out, float* dxyz_out, float* ms) {
+    if (!leg || (n && !xyz)) return fail(LRM_EINVAL, "null input");
+    if ((op == 0 || op == 2) && n && !mask_out) return fail(LRM_EINVAL, "null mask output");
+    if ((op == 1 || op == 2) && n && !dxyz_out) return fail(LRM_EINVAL, "null distance output");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LRM_ENODEV, "no HIP device");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    DevBuf d_in, d_mask, d_out;
+    HIP_TRY(d_in.alloc(n * 3 * sizeof(float)), "hipMalloc gpu_in.elements");
+    const bool want_mask = (op != 1) || mask_out;
+    if (want_mask) HIP_TRY(d_mask.alloc(n), "hipMalloc gpu_out.elements");
+    if (op != 0) HIP_TRY(d_out.alloc(n * 3 * sizeof(float)), "hipMalloc gpu_out.elements");
+    HIP_TRY(hipMemcpy(d_in.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy gpu_in.elements");
+    HIP_TRY(lrm_launch_warmup(n, nullptr), "warm-up launch");
+    Events ev;
+    HIP_TRY(hipEventCreate(&ev.a), "hipEventCreate");
+    HIP_TRY(hipEventCreate(&ev.b), "hipEventCreate");
+    HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
+    if (n) {
+        if (op == 0) HIP_TRY(lrm_launch_reach_aos(d_in.as<float>(), n, L, d_mask.as<uint8_t>(), nullptr), "Kernel launch");
+        else HIP_TRY(lrm_launch_dist_aos(op, d_in.as<float>(), n, L, want_mask ? d_mask.as<uint8_t>() : nullptr,
+                                         d_out.as<float>(), nullptr), "Kernel launch");
+    }
+    HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
+    HIP_TRY(hipEventSynchronize(ev.b), "Kernel launch");
+    float elapsed = 0.f;
+    HIP_TRY(hipEventElapsedTime(&elapsed, ev.a, ev.b), "hipEventElapsedTime");
+    if (want_mask && mask_out) HIP_TRY(hipMemcpy(mask_out, d_mask.p, n, hipMemcpyDeviceToHost), "hipMemcpy gpu_out.elements");
+    if (op != 0) HIP_TRY(hipMemcpy(dxyz_out, d_out.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy gpu_out.elements");
+    HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    if (ms) *ms = elapsed;
+    return LRM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* lrm_version(void) { return "lrm-mi355x 0.1 (gfx950)"; }
+const char* lrm_last_error(void) { return g_err.c_str(); }
+
+int lrm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int lrm_set_device(int ordinal) {
+    HIP_TRY(hipSetDevice(ordinal), "hipSetDevice");
+    return LRM_OK;
+}
+int lrm_set_mode(int mode) {
+    if (mode != LRM_MODE_STRICT && mode != LRM_MODE_FAST) return fail(LRM_EINVAL, "unknown mode");
+    g_mode = mode;
+    return LRM_OK;
+}
+int lrm_get_mode(void) { return g_mode; }
+
+void lrm_leg_factory(float azimut, float body2coxa, float coxa_pitch_deg, float coxa2tibia, float tibia2femur,
+                     float femur2tip, float coxa_angle_deg, float femur_angle_deg, float tibia_angle_deg,
+                     float tib_abs_pos, float tib_abs_neg, LrmLegDimensions* out) {
+    lrm_host_leg_factory(azimut, body2coxa, coxa_pitch_deg, coxa2tibia, tibia2femur, femur2tip, coxa_angle_deg,
+                         femur_angle_deg, tibia_angle_deg, tib_abs_pos, tib_abs_neg, out);
+}
+void lrm_get_M2_leg(float azimut, LrmLegDimensions* out) {
+    lrm_host_leg_factory(azimut, 181, -45, 65.5f, 129, 135, 60.0f, 90.0f, 120.0f, -5, -5, out);
+}
+void lrm_get_moonbot_leg(float azimut, LrmLegDimensions* out) {
+    lrm_host_leg_factory(azimut, 181, 0, 65.5f, 129, 160, 60.0f, 90.0f, 120.0f, -5, -5, out);
+}
+void lrm_rotate_leg_data(const float quat[4], const LrmLegDimensions* leg, LrmLegDimensions* out) {
+    lrm_host_rotate_leg_data(quat, *leg, out);
+}
+
+int lrm_reach(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
+              float* ms) {
+    return host_apply(0, xyz, n, leg, quat, mask_out, nullptr, ms);
+}
+int lrm_dist(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, float* dxyz_out,
+             uint8_t* valid_out, float* ms) {
+    return host_apply(1, xyz, n, leg, quat, valid_out, dxyz_out, ms);
+}
+int lrm_reach_dist(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
+                   float* dxyz_out, float* ms) {
+    return host_apply(2, xyz, n, leg, quat, mask_out, dxyz_out, ms);
+}
+
+// apply_reach_cpu / apply_dist_cpu (cross_compiled.cu:163-181): chrono-timed serial loops
+int lrm_reach_cpu(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
+                  double* ms) {
+    if (!leg || (n && (!xyz || !mask_out))) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    for (size_t i = 0; i < n; i++)
+        mask_out[i] = lrm_reach_global(L, &L.lists[0][0], LrmVec3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]});
+    const auto t1 = std::chrono::high_resolution_clock::now();
+    if (ms) *ms = std::chrono::duration<double>(t1 - t0).count() * 1000.0;
+    return LRM_OK;
+}
+int lrm_dist_cpu(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, float* dxyz_out,
+                 uint8_t* valid_out, double* ms) {
+    if (!leg || (n && (!xyz || !dxyz_out))) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    for (size_t i = 0; i < n; i++) {
+        LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        const bool v = lrm_dist_global(L, &L.lists[0][0], p);
+        dxyz_out[3 * i] = p.x;
+        dxyz_out[3 * i + 1] = p.y;
+        dxyz_out[3 * i + 2] = p.z;
+        if (valid_out) valid_out[i] = v;
+    }
+    const auto t1 = std::chrono::high_resolution_clock::now();
+    if (ms) *ms = std::chrono::duration<double>(t1 - t0).count() * 1000.0;
+    return LRM_OK;
+}
+
+// ---- device-resident entry points ------------------------------------------------------
+int lrm_reach_bits_dev(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
+                       const float* quat, uint8_t* mask, uint64_t* bits, void* stream) {
+    if (!leg || (n && (!x || !y || !z || (!mask && !bits)))) return fail(LRM_EINVAL, "null argument");
+    if (n == 0) return LRM_OK;
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    HIP_TRY(lrm_launch_reach_soa(x, y, z, n, L, mask, bits, (hipStream_t)stream), "reach launch");
+    return LRM_OK;
+}
+int lrm_reach_dev(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
+                  const float* quat, uint8_t* mask, void* stream) {
+    return lrm_reach_bits_dev(x, y, z, n, leg, quat, mask, nullptr, stream);
+}
+int lrm_dist_dev(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
+                 const float* quat, float* dx, float* dy, float* dz, uint8_t* valid, void* stream) {
+    if (!leg || (n && (!x || !y || !z || !dx || !dy || !dz))) return fail(LRM_EINVAL, "null argument");
+    if (n == 0) return LRM_OK;
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    HIP_TRY(lrm_launch_dist_soa(1, x, y, z, n, L, valid, nullptr, dx, dy, dz, (hipStream_t)stream), "dist launch");
+    return LRM_OK;
+}
+int lrm_reach_dist_bits_dev(const float* x, const float* y, const float* z, size_t n,
+                            const LrmLegDimensions* leg, const float* quat, uint8_t* mask, uint64_t* bits,
+                            float* dx, float* dy, float* dz, void* stream) {
+    if (!leg || (n && (!x || !y || !z || (!mask && !bits) || !dx || !dy || !dz)))
+        return fail(LRM_EINVAL, "null argument");
+    if (n == 0) return LRM_OK;
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    HIP_TRY(lrm_launch_dist_soa(2, x, y, z, n, L, mask, bits, dx, dy, dz, (hipStream_t)stream), "reach+dist launch");
+    return LRM_OK;
+}
+int lrm_reach_dist_dev(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
+                       const float* quat, uint8_t* mask, float* dx, float* dy, float* dz, void* stream) {
+    if (n && !mask) return fail(LRM_EINVAL, "null argument");
+    return lrm_reach_dist_bits_dev(x, y, z, n, leg, quat, mask, nullptr, dx, dy, dz, stream);
+}
+int lrm_reach_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask,
+                      void* stream) {
+    if (!leg || (n && (!xyz || !mask))) return fail(LRM_EINVAL, "null argument");
+    if (n == 0) return LRM_OK;
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    HIP_TRY(lrm_launch_reach_aos(xyz, n, L, mask, (hipStream_t)stream), "reach launch");
+    return LRM_OK;
+}
+int lrm_dist_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, float* dxyz,
+                     uint8_t* valid, void* stream) {
+    if (!leg || (n && (!xyz || !dxyz))) return fail(LRM_EINVAL, "null argument");
+    if (n == 0) return LRM_OK;
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    HIP_TRY(lrm_launch_dist_aos(1, xyz, n, L, valid, dxyz, (hipStream_t)stream), "dist launch");
+    return LRM_OK;
+}
+
+// ---- body x target aggregation ---------------------------------------------------------
+namespace {
+// A small per-process pool of device slots for the compiled legs of in-flight launches, so
+// that the launch path does not allocate.  16 slots x LRM_MAX_LEGS; a slot is reused after
+// 16 further launches, far beyond any stream's queue depth in this library's use.
+constexpr int kLegSlots = 16;
+LrmCompiledLeg* g_leg_pool = nullptr;
+int g_leg_pool_dev = -1;
+unsigned g_leg_slot = 0;
+int leg_slot(LrmCompiledLeg** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+    if (!g_leg_pool || g_leg_pool_dev != dev) {
+        // one pool per process and device in use; a device switch re-creates it
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, sizeof(LrmCompiledLeg) * LRM_MAX_LEGS * kLegSlots), "hipMalloc leg pool");
+        g_leg_pool = static_cast<LrmCompiledLeg*>(p);
+        g_leg_pool_dev = dev;
+    }
+    *out = g_leg_pool + (size_t)(g_leg_slot++ % kLegSlots) * LRM_MAX_LEGS;
+    return LRM_OK;
+}
+} // namespace
+
+int lrm_reach_any_dev(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
+                      const float* ty, const float* tz, size_t nt, const LrmLegDimensions* legs, size_t nlegs,
+                      const float* quat, uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream) {
+    if (!legs || nlegs == 0 || nlegs > LRM_MAX_LEGS) return fail(LRM_EINVAL, "nlegs must be 1..LRM_MAX_LEGS");
+    if (!out_leg_body || (nb && (!bx || !by || !bz)) || (nt && (!tx || !ty || !tz)))
+        return fail(LRM_EINVAL, "null argument");
+    if (nb == 0) return LRM_OK;
+    LrmCompiledLeg host_legs[LRM_MAX_LEGS];
+    for (size_t l = 0; l < nlegs; l++) lrm_compile_leg(legs[l], quat_or_default(quat), 0, &host_legs[l]);
+    LrmCompiledLeg* dev_legs = nullptr;
+    int rc = leg_slot(&dev_legs);
+    if (rc != LRM_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(dev_legs, host_legs, sizeof(LrmCompiledLeg) * nlegs, hipMemcpyHostToDevice,
+                           (hipStream_t)stream), "hipMemcpyAsync legs");
+    // pageable-source async copies are staged by the runtime before returning, so host_legs may die
+    HIP_TRY(lrm_launch_reach_any(bx, by, bz, nb, tx, ty, tz, nt, dev_legs, (int)nlegs, out_leg_body, all_legs_out,
+                                 (hipStream_t)stream), "reach_any launch");
+    return LRM_OK;
+}
+
+int lrm_any_in_sphere_dev(const float* cx, const float* cy, const float* cz, size_t nc, const float* tx,
+                          const float* ty, const float* tz, size_t nt, float radius, uint8_t* out, void* stream) {
+    if (!out || (nc && (!cx || !cy || !cz)) || (nt && (!tx || !ty || !tz))) return fail(LRM_EINVAL, "null argument");
+    if (nc == 0) return LRM_OK;
+    HIP_TRY(lrm_launch_any_in_shape(0, cx, cy, cz, nc, tx, ty, tz, nt, radius, 0.f, 0.f, out, (hipStream_t)stream),
+            "in_sphere launch");
+    return LRM_OK;
+}
+int lrm_any_in_cylinder_dev(const float* cx, const float* cy, const float* cz, size_t nc, const float* tx,
+                            const float* ty, const float* tz, size_t nt, float radius, float plus_z, float minus_z,
+                            uint8_t* out, void* stream) {
+    if (!out || (nc && (!cx || !cy || !cz)) || (nt && (!tx || !ty || !tz))) return fail(LRM_EINVAL, "null argument");
+    if (nc == 0) return LRM_OK;
+    HIP_TRY(lrm_launch_any_in_shape(1, cx, cy, cz, nc, tx, ty, tz, nt, radius, plus_z, minus_z, out,
+                                    (hipStream_t)stream), "in_cylinder launch");
+    return LRM_OK;
+}
+
+// ---- diagnostics: lrm_exact_math.h on arrays (host build / device build) -------------------
+int lrm_dbg_exact_math_host(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs) {
+    if (n && (!a || !b || !at2 || !sn || !cs)) return fail(LRM_EINVAL, "null argument");
+    for (size_t i = 0; i < n; i++) {
+        at2[i] = lrm_atan2f(a[i], b[i]);
+        lrm_sincosf(a[i], &sn[i], &cs[i]);
+    }
+    return LRM_OK;
+}
+int lrm_dbg_exact_math_dev(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs,
+                           void* stream) {
+    if (n && (!a || !b || !at2 || !sn || !cs)) return fail(LRM_EINVAL, "null argument");
+    if (n == 0) return LRM_OK;
+    HIP_TRY(lrm_launch_exact_math(a, b, n, at2, sn, cs, (hipStream_t)stream), "exact_math launch");
+    return LRM_OK;
+}
+
+// robot_full_struct's core (several_leg.cu:796-877) as a mask: for each orientation the legs'
+// limits are rotated on the host (several_leg.cu:743-760), bodies AND targets are rotated by the
+// quaternion (rotateData, several_leg.cu:401-411) -- done here on the host copies -- and
+// every leg must find a target; a body is accepted by the first orientation that succeeds.
+int lrm_positionability(const float* bodies, size_t nb, const float* targets, size_t nt,
+                        const LrmLegDimensions* legs, size_t nlegs, const float* quats, size_t nquat,
+                        uint8_t* body_mask_out, float* ms) {
+    if (!legs || nlegs == 0 || nlegs > LRM_MAX_LEGS) return fail(LRM_EINVAL, "nlegs must be 1..LRM_MAX_LEGS");
+    if ((nb && (!bodies || !body_mask_out)) || (nt && !targets) || (nquat && !quats))
+        return fail(LRM_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LRM_ENODEV, "no HIP device");
+    if (nb == 0) return LRM_OK;
+    std::vector<float> hb(3 * nb), ht(3 * (nt ? nt : 1));
+    DevBuf d_b, d_t, d_leg_body, d_all, d_acc;
+    HIP_TRY(d_b.alloc(3 * nb * sizeof(float)), "hipMalloc bodies");
+    HIP_TRY(d_t.alloc(3 * nt * sizeof(float)), "hipMalloc targets");
+    HIP_TRY(d_leg_body.alloc(nlegs * nb), "hipMalloc leg results");
+    HIP_TRY(d_all.alloc(nb), "hipMalloc body results");
+    std::vector<uint8_t> acc(nb, 0), cur(nb);
+    Events ev;
+    HIP_TRY(hipEventCreate(&ev.a), "hipEventCreate");
+    HIP_TRY(hipEventCreate(&ev.b), "hipEventCreate");
+    float total_ms = 0.f;
+    for (size_t qi = 0; qi < nquat; qi++) {
+        const float* q = quats + 4 * qi;
+        LrmCompiledLeg rot;
+        LrmLegDimensions dummy{};
+        lrm_compile_leg(dummy, q, 0, &rot); // only for fwd_rot = qtRotate(q, .)
+        LrmLegDimensions rl[LRM_MAX_LEGS];
+        for (size_t l = 0; l < nlegs; l++) lrm_host_rotate_leg_data(q, legs[l], &rl[l]);
+        // SoA staging of the rotated clouds: [x.. | y.. | z..]
+        for (size_t i = 0; i < nb; i++) {
+            const LrmVec3 r = lrm_qrot(rot.fwd_rot, LrmVec3{bodies[3 * i], bodies[3 * i + 1], bodies[3 * i + 2]});
+            hb[i] = r.x; hb[nb + i] = r.y; hb[2 * nb + i] = r.z;
+        }
+        for (size_t i = 0; i < nt; i++) {
+            const LrmVec3 r = lrm_qrot(rot.fwd_rot, LrmVec3{targets[3 * i], targets[3 * i + 1], targets[3 * i + 2]});
+            ht[i] = r.x; ht[nt + i] = r.y; ht[2 * nt + i] = r.z;
+        }
+        HIP_TRY(hipMemcpy(d_b.p, hb.data(), 3 * nb * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy bodies");
+        if (nt) HIP_TRY(hipMemcpy(d_t.p, ht.data(), 3 * nt * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy targets");
+        HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
+        const float* B = d_b.as<float>();
+        const float* T = d_t.as<float>();
+        int rc = lrm_reach_any_dev(B, B + nb, B + 2 * nb, nb, T, T + nt, T + 2 * nt, nt, rl, nlegs, q,
+                                   d_leg_body.as<uint8_t>(), d_all.as<uint8_t>(), nullptr);
+        if (rc != LRM_OK) return rc;
+        HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
+        HIP_TRY(hipEventSynchronize(ev.b), "reach_any");
+        float e = 0.f;
+        HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
+        total_ms += e;
+        HIP_TRY(hipMemcpy(cur.data(), d_all.p, nb, hipMemcpyDeviceToHost), "hipMemcpy result");
+        for (size_t i = 0; i < nb; i++) acc[i] |= cur[i];
+    }
+    std::memcpy(body_mask_out, acc.data(), nb);
+    if (ms) *ms = total_ms;
+    return LRM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,215 @@
+// lrm_compile.cpp -- hoists every leg-only / orientation-only quantity of the reference's
+// per-point code into one LrmCompiledLeg block (host, once per (leg, quaternion)).
+//
+// The reference recomputes all of this for every point: 4 circles (insert_circles,
+// circles.cu.h:337-383: ~8 sin/cos + 1 sqrt), <=10 corner points (insert_intersecv2,
+// circles.cu.h:417-476: 40 sin/cos), the oriented tibia limits (rotate_leg_data,
+// one_leg_global.cu:48-60) and three sincosf of leg constants.  Computing them here with the
+// same expressions and the same libm calls yields the same floats, so hoisting does not
+// change a single result bit.  Compile without FMA contraction / fast-math.
+#include "lrm_compile.h"
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+constexpr float kPi = 3.14159265358979323846264338327950288419716939937510582097f;
+constexpr double kEps = 0.001; // circles.cu.h:7 (a double literal in the reference)
+
+struct Quat {
+    float x, y, z, w;
+};
+
+// qtInvert, unified_math_cuda.cu.h:29-34
+Quat q_invert(Quat q) {
+    const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    return Quat{q.x / n2, -q.y / n2, -q.z / n2, -q.w / n2};
+}
+
+// qtMultiply, unified_math_cuda.cu.h:40-46
+Quat q_mul(Quat a, Quat b) {
+    Quat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return r;
+}
+
+// quatFromVectAngle, unified_math_cuda.cu.h:48-57, for the z axis
+Quat q_about_z(float angle) {
+    float s, c;
+    sincosf(angle / 2, &s, &c);
+    const float mag = sqrtf(0.f * 0.f + 0.f * 0.f + 1.f * 1.f);
+    return Quat{s, c * 0.f / mag, c * 0.f / mag, c * 1.f / mag};
+}
+
+// the nine coefficient sums of qtRotate, unified_math_cuda.cu.h:13-27
+void rot_coefficients(Quat q, float m[9]) {
+    const float t2 = q.x * q.y, t3 = q.x * q.z, t4 = q.x * q.w;
+    const float t5 = -q.y * q.y, t6 = q.y * q.z, t7 = q.y * q.w;
+    const float t8 = -q.z * q.z, t9 = q.z * q.w, t10 = -q.w * q.w;
+    m[0] = t8 + t10; m[1] = t6 - t4; m[2] = t3 + t7;
+    m[3] = t4 + t6;  m[4] = t5 + t10; m[5] = t9 - t2;
+    m[6] = t7 - t3;  m[7] = t2 + t9; m[8] = t5 + t8;
+}
+
+// pitch component of rpyFromQuat, unified_math_cuda.cu.h:59-83
+float pitch_of(Quat q) {
+    const double sinp = 2 * (q.w * q.y - q.z * q.x); // float product, widened
+    if (std::fabs(sinp) >= 1) return copysignf((float)(M_PI / 2), (float)sinp);
+    return (float)std::asin(sinp);
+}
+
+LrmCircle circle(float x, float y, float r, bool attract) { return LrmCircle{x, y, r, attract ? 1.f : 0.f}; }
+
+// circles.cu.h:80-135 + leg_geometry.cu.h:12-50
+LrmCircle inner(const LrmLegDimensions& l) {
+    const float x = l.femur_length + l.tibia_length * cosf(l.min_angle_tibia);
+    const float y = l.tibia_length * sinf(l.min_angle_tibia);
+    return circle(0.f, 0.f, sqrtf(x * x + y * y), false);
+}
+LrmCircle outer(const LrmLegDimensions& l) { return circle(0.f, 0.f, l.tibia_length + l.femur_length, true); }
+LrmCircle from_above(const LrmLegDimensions& l, bool positive) {
+    const float a = positive ? l.tibia_absolute_pos : l.tibia_absolute_neg;
+    return circle(l.tibia_length * cosf(a), l.tibia_length * sinf(a), l.femur_length, false);
+}
+LrmCircle winglet(const LrmLegDimensions& l, bool lower_side) {
+    const float a = lower_side ? l.min_angle_femur : l.max_angle_femur;
+    return circle(cosf(a) * l.femur_length, sinf(a) * l.femur_length, l.tibia_length, false);
+}
+
+// The leg-only half of find_region (circles.cu.h:56-68) for a given UpperRegion bit.
+struct SideFlags {
+    bool femur_limits;       // FemurAngleLimitation
+    bool femur_limits_other; // FemurAngleLimitation_other
+    float full_sat;          // full_sat_limit
+};
+SideFlags side_flags(const LrmLegDimensions& d, bool upper) {
+    const float femur_limit = upper ? d.max_angle_femur : d.min_angle_femur;
+    const float abs_limit = upper ? d.tibia_absolute_pos : d.tibia_absolute_neg;
+    const float femur_limit_o = !upper ? d.max_angle_femur : d.min_angle_femur;
+    const float abs_limit_o = !upper ? d.tibia_absolute_pos : d.tibia_absolute_neg;
+    SideFlags f;
+    f.femur_limits = (!upper) != (femur_limit < abs_limit);
+    f.femur_limits_other = (!upper) != (femur_limit_o < abs_limit_o);
+    f.full_sat = f.femur_limits ? femur_limit : abs_limit;
+    return f;
+}
+
+// insert_circles (MegaClamp == 0), circles.cu.h:337-383, for one of the 4 possible regions
+void circle_list(const LrmLegDimensions& l, bool upper, bool fully_ext, LrmCircle out[4]) {
+    const SideFlags f = side_flags(l, upper);
+    out[0] = inner(l);
+    LrmCircle* tail = out + 1; // [0] fromabove_neg slot, [1] fromabove_pos slot, [2] winglet slot
+    tail[0] = from_above(l, false);
+    tail[1] = from_above(l, true);
+    const int excluded = upper ? 0 : 1;
+    if (f.femur_limits_other) tail[excluded] = winglet(l, /*lower_side=*/upper);
+    tail[excluded].attract = 0.f;
+    const int other = upper ? 1 : 0;
+    tail[2] = winglet(l, /*lower_side=*/!upper);
+    tail[other].attract = f.femur_limits ? 0.f : 1.f;
+    tail[2].attract = f.femur_limits ? 1.f : 0.f;
+    if (fully_ext) tail[(tail[other].attract != 0.f) ? other : 2] = outer(l);
+}
+
+// insert_intersecv2, circles.cu.h:417-476
+int corner_points(const LrmLegDimensions& l, float* xs, float* ys) {
+    const float fem[10] = {l.min_angle_femur, l.min_angle_femur, l.min_angle_femur,
+                           l.tibia_absolute_neg - l.min_angle_tibia,
+                           l.tibia_absolute_neg - l.max_angle_tibia,
+                           l.max_angle_femur, l.max_angle_femur, l.max_angle_femur,
+                           l.tibia_absolute_pos - l.min_angle_tibia,
+                           l.tibia_absolute_pos - l.min_angle_tibia};
+    const float tib[10] = {l.max_angle_tibia, l.min_angle_tibia, l.tibia_absolute_neg - fem[2],
+                           l.tibia_absolute_neg - fem[3], l.tibia_absolute_neg - fem[4],
+                           l.min_angle_tibia, l.max_angle_tibia, l.tibia_absolute_pos - fem[7],
+                           l.tibia_absolute_pos - fem[8], l.tibia_absolute_pos - fem[9]};
+    int n = 0;
+    for (int i = 0; i < 10; i++) {
+        const float f = fem[i], t = tib[i], a = f + t;
+        const bool ok = ((double)f < (double)l.max_angle_femur + kEps) && ((double)f > (double)l.min_angle_femur - kEps) &&
+                        ((double)t < (double)l.max_angle_tibia + kEps) && ((double)t > (double)l.min_angle_tibia - kEps) &&
+                        ((double)a < (double)l.tibia_absolute_pos + kEps) && ((double)a > (double)l.tibia_absolute_neg - kEps);
+        if (!ok) continue;
+        const float xf = l.femur_length * cosf(f), yf = l.femur_length * sinf(f);
+        const float xt = l.tibia_length * cosf(a), yt = l.tibia_length * sinf(a);
+        xs[n] = xf + xt;
+        ys[n] = yf + yt;
+        n++;
+    }
+    return n;
+}
+
+} // namespace
+
+void lrm_host_rotate_leg_data(const float quat[4], const LrmLegDimensions& leg, LrmLegDimensions* out) {
+    const Quat q{quat[0], quat[1], quat[2], quat[3]};
+    const Quat qa = q_about_z(leg.body_angle);
+    const float pitch = pitch_of(q_mul(q_mul(qa, q), q_invert(qa)));
+    *out = leg;
+    out->tibia_absolute_pos -= pitch;
+    out->tibia_absolute_neg -= pitch;
+}
+
+void lrm_host_leg_factory(float azimut, float body2coxa, float coxa_pitch_deg, float coxa2tibia,
+                          float tibia2femur, float femur2tip, float coxa_angle_deg,
+                          float femur_angle_deg, float tibia_angle_deg, float tib_abs_pos,
+                          float tib_abs_neg, LrmLegDimensions* out) {
+    // leg_factory, static_variables.cpp:6-42
+    LrmLegDimensions leg;
+    std::memset(&leg, 0, sizeof leg);
+    leg.coxa_pitch = coxa_pitch_deg / 180.f * kPi;
+    leg.body = body2coxa;
+    leg.coxa_length = coxa2tibia;
+    leg.femur_length = tibia2femur;
+    leg.tibia_length = femur2tip;
+    leg.tibia_absolute_pos = tib_abs_pos / 180.0f * kPi - leg.coxa_pitch;
+    leg.tibia_absolute_neg = (-180.0f - tib_abs_neg) / 180.0f * kPi - leg.coxa_pitch;
+    leg.max_angle_coxa = kPi / 180.0f * coxa_angle_deg;
+    leg.min_angle_coxa = -kPi / 180.0f * coxa_angle_deg;
+    leg.max_angle_femur = kPi / 180.0f * femur_angle_deg;
+    leg.min_angle_femur = -kPi / 180.0f * femur_angle_deg;
+    leg.max_angle_tibia = kPi / 180.0f * tibia_angle_deg;
+    leg.min_angle_tibia = -kPi / 180.0f * tibia_angle_deg;
+    leg.body_angle = azimut;
+    *out = leg;
+}
+
+void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int apply_leg_rotation,
+                     LrmCompiledLeg* out) {
+    std::memset(out, 0, sizeof *out);
+    LrmLegDimensions l = leg_in;
+    if (apply_leg_rotation) lrm_host_rotate_leg_data(quat, leg_in, &l);
+    const Quat q{quat[0], quat[1], quat[2], quat[3]};
+
+    for (int u = 0; u < 2; u++)
+        for (int fe = 0; fe < 2; fe++) circle_list(l, u != 0, fe != 0, out->lists[u * 2 + fe]);
+    out->n_corners = corner_points(l, out->corner_x, out->corner_y);
+
+    rot_coefficients(q_invert(q), out->inv_rot);
+    rot_coefficients(q, out->fwd_rot);
+    sincosf(-l.body_angle, &out->sin_body, &out->cos_body);
+    out->body = l.body;
+    sincosf(-l.coxa_pitch, &out->sin_pitch, &out->cos_pitch);
+    sincosf(l.coxa_pitch, &out->sin_pitch_rev, &out->cos_pitch_rev);
+    out->coxa_length = l.coxa_length;
+    out->max_coxa = l.max_angle_coxa;
+    out->min_coxa = l.min_angle_coxa;
+    out->mega_hi = l.max_angle_coxa + kPi / 2;
+    out->mega_lo = l.min_angle_coxa - kPi / 2;
+    out->coxa_mid = (l.max_angle_coxa + l.min_angle_coxa) / 2;
+    // circles.cu.h:52-54 (std::max / std::min)
+    const float lo = (l.tibia_absolute_neg < l.min_angle_femur) ? l.min_angle_femur : l.tibia_absolute_neg;
+    const float hi = (l.max_angle_femur < l.tibia_absolute_pos) ? l.max_angle_femur : l.tibia_absolute_pos;
+    out->region_mid = (lo + hi) / 2;
+    out->full_sat[0] = side_flags(l, false).full_sat;
+    out->full_sat[1] = side_flags(l, true).full_sat;
+
+    // Nothing farther than the stretched leg (+1 mm and 1e-4 relative slack, three orders of
+    // magnitude above the float rounding of the strict evaluation) can pass the attractive
+    // circle test, so pairs beyond this radius are skipped without changing any result.
+    const float reach = l.body + l.coxa_length + l.femur_length + l.tibia_length + 1.0f;
+    out->reach_r2_max = reach * reach * 1.0001f;
+}

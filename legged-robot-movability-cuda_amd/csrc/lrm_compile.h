@@ -1,0 +1,17 @@
+// lrm_compile.h -- host side: (LegDimensions, quaternion) -> LrmCompiledLeg.
+#pragma once
+#include "lrm_types.h"
+
+// apply_leg_rotation != 0: the tibia limits are first rotated by the pitch of the body
+// orientation seen from the leg (rotate_leg_data, one_leg_global.cu:48-60), as
+// reachability_global / distance_global do.  == 0: the leg is used as given
+// (reach_mem_kernel receives legs the host already rotated, several_leg.cu:743-760).
+void lrm_compile_leg(const LrmLegDimensions& leg, const float quat[4], int apply_leg_rotation,
+                     LrmCompiledLeg* out);
+
+// host helpers shared with the C ABI
+void lrm_host_rotate_leg_data(const float quat[4], const LrmLegDimensions& leg, LrmLegDimensions* out);
+void lrm_host_leg_factory(float azimut, float body2coxa, float coxa_pitch_deg, float coxa2tibia,
+                          float tibia2femur, float femur2tip, float coxa_angle_deg,
+                          float femur_angle_deg, float tibia_angle_deg, float tib_abs_pos,
+                          float tib_abs_neg, LrmLegDimensions* out);

@@ -1,0 +1,394 @@
+// lrm_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the reach / distance path.
+//
+// Layout in HBM: coordinates SoA (x[], y[], z[] float32), mask one byte per point (the
+// reference's Array<bool>), optional ballot bit mask (uint64 per 64 points), distance field
+// SoA.  AoS variants exist only for the drop-in apply_kernel boundary.
+//
+// The per-(leg, orientation) constants travel as ONE kernel argument (LrmCompiledLeg, by
+// value): wave-uniform scalars are read through the scalar cache into SGPRs, and the only
+// per-lane-indexed table (the 4 region circle lists, 256 B) is staged in LDS so that a lane
+// fetches a circle with one ds_read_b128.  No MFMA: this is elementwise geometry.
+//
+// Compiled with -ffp-contract=off (see lrm_point.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lrm_launch.h"
+#include "lrm_point.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ void stage_lists(const LrmCompiledLeg& L, LrmCircle* s_lists) {
+    // 16 circles x 4 floats; one float per thread
+    const float* src = reinterpret_cast<const float*>(&L.lists[0][0]);
+    float* dst = reinterpret_cast<float*>(s_lists);
+    if (threadIdx.x < 64) dst[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------
+// reachability_global_kernel (one_leg_global.cu:149-156), 4 consecutive points per lane:
+// three 16-byte loads in, one 4-byte store out.
+// ------------------------------------------------------------------------------------
+template <bool kBits>
+__global__ __launch_bounds__(kBlock) void reach_soa_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ y,
+                                                           const float* __restrict__ z, size_t n,
+                                                           const LrmCompiledLeg L,
+                                                           uint8_t* __restrict__ mask,
+                                                           uint64_t* __restrict__ bits) {
+    __shared__ LrmCircle s_lists[16];
+    stage_lists(L, s_lists);
+    const size_t nquad = n >> 2;
+    // every wave runs the same number of iterations so that the shuffles below see all lanes
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t nquad_pad = (nquad + 63) & ~(size_t)63;
+    for (size_t qd = (size_t)blockIdx.x * kBlock + threadIdx.x; qd < nquad_pad; qd += stride) {
+        uint32_t packed = 0;
+        if (qd < nquad) {
+            const float4 vx = reinterpret_cast<const float4*>(x)[qd];
+            const float4 vy = reinterpret_cast<const float4*>(y)[qd];
+            const float4 vz = reinterpret_cast<const float4*>(z)[qd];
+            const bool r0 = lrm_reach_global(L, s_lists, LrmVec3{vx.x, vy.x, vz.x});
+            const bool r1 = lrm_reach_global(L, s_lists, LrmVec3{vx.y, vy.y, vz.y});
+            const bool r2 = lrm_reach_global(L, s_lists, LrmVec3{vx.z, vy.z, vz.z});
+            const bool r3 = lrm_reach_global(L, s_lists, LrmVec3{vx.w, vy.w, vz.w});
+            packed = (uint32_t)r0 | ((uint32_t)r1 << 8) | ((uint32_t)r2 << 16) | ((uint32_t)r3 << 24);
+            if (mask) reinterpret_cast<uint32_t*>(mask)[qd] = packed;
+        }
+        if (kBits) {
+            // 16 lanes x 4 points = one 64-bit word
+            const uint32_t nib = (packed & 1u) | ((packed >> 7) & 2u) | ((packed >> 14) & 4u) | ((packed >> 21) & 8u);
+            const int sub = threadIdx.x & 15;
+            uint64_t w = (uint64_t)nib << (4 * sub);
+            w |= __shfl_xor(w, 1);
+            w |= __shfl_xor(w, 2);
+            w |= __shfl_xor(w, 4);
+            w |= __shfl_xor(w, 8);
+            if (sub == 0 && (qd >> 4) < (n >> 6)) bits[qd >> 4] = w; // full words only
+        }
+    }
+    // tail: n % 4 points, handled by the first lanes of block 0
+    const size_t tail0 = nquad << 2;
+    if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
+        const size_t i = tail0 + threadIdx.x;
+        const bool r = lrm_reach_global(L, s_lists, LrmVec3{x[i], y[i], z[i]});
+        if (mask) mask[i] = r;
+    }
+    if (kBits && blockIdx.x == 0 && threadIdx.x == 0 && (n & 63)) {
+        // the last (partial) word: rebuild it from scratch so that unused bits are 0
+        const size_t w0 = n & ~(size_t)63;
+        uint64_t w = 0;
+        for (size_t i = w0; i < n; i++)
+            w |= (uint64_t)lrm_reach_global(L, s_lists, LrmVec3{x[i], y[i], z[i]}) << (i - w0);
+        bits[w0 >> 6] = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// distance_global_kernel (one_leg_global.cu:157-166) and the fused reach+distance kernel:
+// one point per lane per iteration (the distance code is long: keep one copy of it).
+// kOp: 1 = distance (+ optional validity byte), 2 = reach mask + distance.
+// ------------------------------------------------------------------------------------
+template <int kOp>
+__global__ __launch_bounds__(kBlock) void dist_soa_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ y,
+                                                          const float* __restrict__ z, size_t n,
+                                                          const LrmCompiledLeg L,
+                                                          uint8_t* __restrict__ mask,
+                                                          uint64_t* __restrict__ bits,
+                                                          float* __restrict__ dx,
+                                                          float* __restrict__ dy,
+                                                          float* __restrict__ dz) {
+    __shared__ LrmCircle s_lists[16];
+    stage_lists(L, s_lists);
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t n_pad = (n + 63) & ~(size_t)63; // whole waves iterate together (ballot below)
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
+        bool m = false;
+        if (i < n) {
+            LrmVec3 p{x[i], y[i], z[i]};
+            if (kOp == 2) m = lrm_reach_global(L, s_lists, p);
+            const bool v = lrm_dist_global(L, s_lists, p);
+            dx[i] = p.x;
+            dy[i] = p.y;
+            dz[i] = p.z;
+            if (kOp != 2) m = v;
+            if (mask) mask[i] = m;
+        }
+        if (bits) { // wave64 ballot: lane l of this wave holds point (i & ~63) + l
+            const uint64_t w = __ballot(m);
+            if ((threadIdx.x & 63) == 0) bits[i >> 6] = w;
+        }
+    }
+}
+
+// AoS variants for the apply_kernel boundary (cross_compiled.cu:33-79)
+__global__ __launch_bounds__(kBlock) void reach_aos_kernel(const float* __restrict__ xyz, size_t n,
+                                                           const LrmCompiledLeg L,
+                                                           uint8_t* __restrict__ mask) {
+    __shared__ LrmCircle s_lists[16];
+    stage_lists(L, s_lists);
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        mask[i] = lrm_reach_global(L, s_lists, p);
+    }
+}
+
+template <int kOp>
+__global__ __launch_bounds__(kBlock) void dist_aos_kernel(const float* __restrict__ xyz, size_t n,
+                                                          const LrmCompiledLeg L,
+                                                          uint8_t* __restrict__ mask,
+                                                          float* __restrict__ dxyz) {
+    __shared__ LrmCircle s_lists[16];
+    stage_lists(L, s_lists);
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        bool m = false;
+        if (kOp == 2) m = lrm_reach_global(L, s_lists, p);
+        const bool v = lrm_dist_global(L, s_lists, p);
+        dxyz[3 * i] = p.x;
+        dxyz[3 * i + 1] = p.y;
+        dxyz[3 * i + 2] = p.z;
+        if (mask) mask[i] = (kOp == 2) ? m : v;
+    }
+}
+
+// empty_kernel, cuda_util.cu:3 (the warm-up launch of apply_kernel, cross_compiled.cu:52)
+__global__ void warmup_kernel() {}
+
+// ------------------------------------------------------------------------------------
+// Body x target aggregation: reach_mem_kernel (several_leg.cu:92-129) for all legs and
+// all targets in ONE launch.
+//   grid  = (ceil(nb / kBodiesPerBlock), nlegs), block = 256 threads = 4 waves
+//   a wave owns kBodiesPerWave bodies; lane = target inside a 64-target slice of the
+//   LDS-staged target tile; __ballot over the wave is the "any" reduction, and a body that
+//   already has a reachable target is never evaluated again (early exit per body, per
+//   wave, per block).
+// Each (body, target) pair first passes a conservative sphere test (|t - b|^2 against the
+// leg's total length, with slack): pairs outside cannot be reachable, so skipping them does
+// not change any output bit.
+// ------------------------------------------------------------------------------------
+constexpr int kWaves = kBlock / 64;
+constexpr int kBodiesPerWave = 4;
+constexpr int kBodiesPerBlock = kWaves * kBodiesPerWave;
+constexpr int kTargetTile = 1024;
+
+__global__ __launch_bounds__(kBlock) void reach_any_kernel(
+    const float* __restrict__ bx, const float* __restrict__ by, const float* __restrict__ bz, size_t nb,
+    const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, size_t nt,
+    const LrmCompiledLeg* __restrict__ legs, uint8_t* __restrict__ out) {
+    __shared__ LrmCircle s_lists[16];
+    __shared__ float s_tx[kTargetTile], s_ty[kTargetTile], s_tz[kTargetTile];
+    __shared__ int s_todo; // waves of this block that still have an unsatisfied body
+
+    const LrmCompiledLeg& L = legs[blockIdx.y];
+    stage_lists(L, s_lists);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t body0 = (size_t)blockIdx.x * kBodiesPerBlock + (size_t)wave * kBodiesPerWave;
+
+    LrmVec3 body[kBodiesPerWave];
+    bool found[kBodiesPerWave];
+#pragma unroll
+    for (int k = 0; k < kBodiesPerWave; k++) {
+        const size_t b = body0 + k;
+        const bool live = b < nb;
+        body[k] = live ? LrmVec3{bx[b], by[b], bz[b]} : LrmVec3{0.f, 0.f, 0.f};
+        found[k] = !live; // out-of-range bodies need no work
+    }
+    const float r2max = L.reach_r2_max;
+
+    for (size_t t0 = 0; t0 < nt; t0 += kTargetTile) {
+        const int tile_n = (int)((nt - t0 < (size_t)kTargetTile) ? (nt - t0) : (size_t)kTargetTile);
+        __syncthreads(); // previous tile fully consumed
+        if (threadIdx.x == 0) s_todo = 0;
+        for (int i = threadIdx.x; i < tile_n; i += kBlock) {
+            s_tx[i] = tx[t0 + i];
+            s_ty[i] = ty[t0 + i];
+            s_tz[i] = tz[t0 + i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kBodiesPerWave; k++) {
+            if (found[k]) continue; // wave-uniform
+            for (int s = 0; s < tile_n; s += 64) {
+                const int i = s + lane;
+                bool hit = false;
+                if (i < tile_n) {
+                    const LrmVec3 t{s_tx[i], s_ty[i], s_tz[i]};
+                    const float ddx = t.x - body[k].x, ddy = t.y - body[k].y, ddz = t.z - body[k].z;
+                    const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                    if (d2 <= r2max) hit = lrm_reachable_rotate_leg(L, s_lists, t, body[k]);
+                }
+                if (__ballot(hit) != 0ull) {
+                    found[k] = true;
+                    break;
+                }
+            }
+        }
+        bool wave_todo = false;
+#pragma unroll
+        for (int k = 0; k < kBodiesPerWave; k++) wave_todo = wave_todo || !found[k];
+        if (lane == 0 && wave_todo) atomicAdd(&s_todo, 1);
+        __syncthreads();
+        if (s_todo == 0) break; // block-uniform: every body of this block is satisfied
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < kBodiesPerWave; k++) {
+            const size_t b = body0 + k;
+            if (b < nb) out[(size_t)blockIdx.y * nb + b] = found[k] ? 1 : 0;
+        }
+    }
+}
+
+// agregateReachability (several_leg.cu:681-697) for any number of legs: AND over legs
+__global__ __launch_bounds__(kBlock) void and_legs_kernel(const uint8_t* __restrict__ leg_body, size_t nb,
+                                                          int nlegs, uint8_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x; b < nb; b += stride) {
+        uint8_t v = 1;
+        for (int l = 0; l < nlegs; l++) v &= leg_body[(size_t)l * nb + b];
+        out[b] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// in_sphere_mem_kernel / in_cylinder_mem_kernel (collision.cu:40-66, :119-146) in one
+// launch each: out[c] = any target inside the sphere / cylinder centred on c.
+// kShape: 0 sphere (collision.cu.h:5-10), 1 cylinder (collision.cu.h:12-23).
+// ------------------------------------------------------------------------------------
+template <int kShape>
+__global__ __launch_bounds__(kBlock) void any_in_shape_kernel(
+    const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz, size_t nc,
+    const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, size_t nt,
+    float radius, float plus_z, float minus_z, uint8_t* __restrict__ out) {
+    __shared__ float s_tx[kTargetTile], s_ty[kTargetTile], s_tz[kTargetTile];
+    // one centre per thread, the whole block sweeps the same LDS tile (broadcast reads)
+    const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = c < nc;
+    const float px = live ? cx[c] : 0.f, py = live ? cy[c] : 0.f, pz = live ? cz[c] : 0.f;
+    bool found = false;
+    for (size_t t0 = 0; t0 < nt; t0 += kTargetTile) {
+        const int tile_n = (int)((nt - t0 < (size_t)kTargetTile) ? (nt - t0) : (size_t)kTargetTile);
+        __syncthreads();
+        for (int i = threadIdx.x; i < tile_n; i += kBlock) {
+            s_tx[i] = tx[t0 + i];
+            s_ty[i] = ty[t0 + i];
+            s_tz[i] = tz[t0 + i];
+        }
+        __syncthreads();
+        if (live && !found) {
+            for (int i = 0; i < tile_n; i++) {
+                bool in;
+                if (kShape == 0) {
+                    const float ax = px - s_tx[i], ay = py - s_ty[i], az = pz - s_tz[i];
+                    in = sqrtf(ax * ax + ay * ay + az * az) < radius;
+                } else {
+                    const float dzz = s_tz[i] - pz;
+                    const float ax = s_tx[i] - px, ay = s_ty[i] - py;
+                    in = (sqrtf(ax * ax + ay * ay + 0.f) < radius) && (dzz < plus_z) && (dzz > minus_z);
+                }
+                if (in) { found = true; break; }
+            }
+        }
+    }
+    if (live) out[c] = found ? 1 : 0;
+}
+
+// diagnostic: the device build of lrm_exact_math.h on arrays (tests compare it with glibc)
+__global__ __launch_bounds__(kBlock) void exact_math_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            size_t n, float* __restrict__ at2,
+                                                            float* __restrict__ sn, float* __restrict__ cs) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        at2[i] = lrm_atan2f(a[i], b[i]);
+        float s, c;
+        lrm_sincosf(a[i], &s, &c);
+        sn[i] = s;
+        cs[i] = c;
+    }
+}
+
+inline int grid_for(size_t work_items) {
+    // memory-streaming launches: enough workgroups to fill 256 CUs x 8, grid-stride the rest
+    size_t g = (work_items + kBlock - 1) / kBlock;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+} // namespace
+
+// ---- launch functions (declared in lrm_launch.h) ---------------------------------------
+hipError_t lrm_launch_warmup(size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(warmup_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st);
+    return hipGetLastError();
+}
+
+hipError_t lrm_launch_reach_soa(const float* x, const float* y, const float* z, size_t n,
+                                const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, hipStream_t st) {
+    const int grid = grid_for((n + 3) / 4);
+    if (bits) hipLaunchKernelGGL(reach_soa_kernel<true>, dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
+    else hipLaunchKernelGGL(reach_soa_kernel<false>, dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
+    return hipGetLastError();
+}
+
+hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const float* z, size_t n,
+                               const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
+                               float* dz, hipStream_t st) {
+    const int grid = grid_for(n);
+    if (op == 2) hipLaunchKernelGGL(dist_soa_kernel<2>, dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
+    else hipLaunchKernelGGL(dist_soa_kernel<1>, dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
+    return hipGetLastError();
+}
+
+hipError_t lrm_launch_reach_aos(const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask, hipStream_t st) {
+    hipLaunchKernelGGL(reach_aos_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask);
+    return hipGetLastError();
+}
+
+hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask,
+                               float* dxyz, hipStream_t st) {
+    if (op == 2) hipLaunchKernelGGL(dist_aos_kernel<2>, dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask, dxyz);
+    else hipLaunchKernelGGL(dist_aos_kernel<1>, dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask, dxyz);
+    return hipGetLastError();
+}
+
+hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
+                                const float* ty, const float* tz, size_t nt, const LrmCompiledLeg* legs_dev,
+                                int nlegs, uint8_t* out_leg_body, uint8_t* all_legs_out, hipStream_t st) {
+    const dim3 grid((unsigned)((nb + kBodiesPerBlock - 1) / kBodiesPerBlock), (unsigned)nlegs);
+    hipLaunchKernelGGL(reach_any_kernel, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev,
+                       out_leg_body);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (all_legs_out) {
+        hipLaunchKernelGGL(and_legs_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, st, out_leg_body, nb, nlegs,
+                           all_legs_out);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, const float* cz, size_t nc,
+                                   const float* tx, const float* ty, const float* tz, size_t nt, float radius,
+                                   float plus_z, float minus_z, uint8_t* out, hipStream_t st) {
+    const dim3 grid((unsigned)((nc + kBlock - 1) / kBlock));
+    if (shape == 0)
+        hipLaunchKernelGGL(any_in_shape_kernel<0>, grid, dim3(kBlock), 0, st, cx, cy, cz, nc, tx, ty, tz, nt, radius,
+                           plus_z, minus_z, out);
+    else
+        hipLaunchKernelGGL(any_in_shape_kernel<1>, grid, dim3(kBlock), 0, st, cx, cy, cz, nc, tx, ty, tz, nt, radius,
+                           plus_z, minus_z, out);
+    return hipGetLastError();
+}
+
+hipError_t lrm_launch_exact_math(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(exact_math_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, a, b, n, at2, sn, cs);
+    return hipGetLastError();
+}

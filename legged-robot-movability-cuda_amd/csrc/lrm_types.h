@@ -1,0 +1,51 @@
+// lrm_types.h -- host/device shared plain-old-data of the MI355X reach/distance path.
+#pragma once
+#include <stdint.h>
+#include "../../include/lrm.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LRM_HD __host__ __device__ __forceinline__
+#else
+#define LRM_HD inline
+#endif
+
+#define LRM_N_CIRCLES 4  // circles.cu.h:8-14 MAX_CIRCLES
+#define LRM_N_CORNERS 10 // circles.cu.h:15 MAX_INTERSECT
+
+// Circle, HeaderCPP.h:9-15, widened to 16 B so that one ds_read_b128 fetches it.
+// attract: 1.0f = the point must lie inside, 0.0f = outside.
+struct LrmCircle {
+    float x, y, r, attract;
+};
+
+// Everything the per-point code needs that depends only on (leg, body orientation).
+// The reference rebuilds all of it for every point (insert_circles circles.cu.h:337-383,
+// insert_intersecv2 :417-476, rotate_leg_data one_leg_global.cu:48-60, the sincosf of
+// coxa_pitch / body_angle); here the host computes it once per (leg, quaternion) with the
+// reference's own expressions and libm calls, so the values are the same floats.
+struct LrmCompiledLeg {
+    // circle list for region (upper, fully_extended): lists[upper*2 + fe][0..3]
+    LrmCircle lists[4][LRM_N_CIRCLES];
+    // corner points that survive the joint-limit filter, in reference order
+    float corner_x[LRM_N_CORNERS];
+    float corner_y[LRM_N_CORNERS];
+    int32_t n_corners;
+    // qtRotate(qtInvert(q), .) and qtRotate(q, .) coefficient sums, row-major 3x3:
+    //   out.x = 2*(m[0]*x + m[1]*y + m[2]*z) + x   (unified_math_cuda.cu.h:13-27)
+    float inv_rot[9];
+    float fwd_rot[9];
+    float cos_body, sin_body;           // sincosf(-body_angle)   one_leg_global.cu:62-67
+    float body;                         // one_leg.cu:13
+    float cos_pitch, sin_pitch;         // sincosf(-coxa_pitch)   one_leg.cu:19
+    float cos_pitch_rev, sin_pitch_rev; // sincosf(+coxa_pitch)   one_leg.cu:17
+    float coxa_length;                  // one_leg.cu:172
+    float max_coxa, min_coxa;           // one_leg.cu:305-306
+    float mega_hi, mega_lo;             // max_coxa + PI/2, min_coxa - PI/2  one_leg.cu:219-220
+    float coxa_mid;                     // (max_coxa + min_coxa)/2           one_leg.cu:229
+    float region_mid;                   // circles.cu.h:52-54
+    float full_sat[2];                  // circles.cu.h:68, indexed by UpperRegion
+    // ---- derived constants of the filtered (LRM_MODE_FAST) evaluation ----
+    float reach_r2_max;                 // (body-frame) squared radius beyond which nothing is reachable
+    float pad[2];
+};

@@ -1,0 +1,129 @@
+"""Device-resident entry points on torch CUDA(ROCm) tensors.  torch only owns the memory and
+the stream; every computation is a liblrm.so kernel launched on torch's current stream."""
+import numpy as np
+
+from . import _capi
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return _torch().cuda.current_stream().cuda_stream
+
+
+def _check_f32(*ts):
+    torch = _torch()
+    n = ts[0].numel()
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+            raise ValueError("expected contiguous float32 CUDA tensors of equal length")
+        if t.data_ptr() % 16:
+            raise ValueError("coordinate arrays must be 16-byte aligned")
+    return n
+
+
+def _leg(leg):
+    return np.ascontiguousarray(leg, dtype=np.float32).reshape(-1)
+
+
+def _q(quat):
+    return None if quat is None else np.ascontiguousarray(quat, dtype=np.float32).reshape(4)
+
+
+def reach(x, y, z, leg, quat=None, out=None, bits=None, want_bits=False):
+    """mask[i] = reachability_global(point i) (one byte per point); optionally also the
+    ballot bit mask (int64 words, bit i&63 of word i>>6)."""
+    torch = _torch()
+    n = _check_f32(x, y, z)
+    if out is None:
+        out = torch.empty(n, dtype=torch.uint8, device=x.device)
+    if want_bits and bits is None:
+        bits = torch.empty((n + 63) // 64, dtype=torch.int64, device=x.device)
+    leg = _leg(leg)
+    q = _q(quat)
+    L = _capi.load()
+    if bits is not None:
+        _capi.check(L.lrm_reach_bits_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q), _dp(out),
+                                         _dp(bits), _stream()))
+        return out, bits
+    _capi.check(L.lrm_reach_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q), _dp(out), _stream()))
+    return out
+
+
+def dist(x, y, z, leg, quat=None, out=None, valid=None, want_valid=True):
+    torch = _torch()
+    n = _check_f32(x, y, z)
+    if out is None:
+        out = torch.empty((3, n), dtype=torch.float32, device=x.device)
+    if valid is None and want_valid:
+        valid = torch.empty(n, dtype=torch.uint8, device=x.device)
+    leg = _leg(leg)
+    q = _q(quat)
+    _capi.check(_capi.load().lrm_dist_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q), _dp(out[0]),
+                                          _dp(out[1]), _dp(out[2]), _dp(valid), _stream()))
+    return out, valid
+
+
+def reach_dist(x, y, z, leg, quat=None, mask=None, out=None, bits=None):
+    """One launch: reach mask (bytes and/or ballot bit words) + distance field (3, n)."""
+    torch = _torch()
+    n = _check_f32(x, y, z)
+    if out is None:
+        out = torch.empty((3, n), dtype=torch.float32, device=x.device)
+    if mask is None and bits is None:
+        mask = torch.empty(n, dtype=torch.uint8, device=x.device)
+    leg = _leg(leg)
+    q = _q(quat)
+    _capi.check(_capi.load().lrm_reach_dist_bits_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q),
+                                                     _dp(mask), _dp(bits), _dp(out[0]), _dp(out[1]), _dp(out[2]),
+                                                     _stream()))
+    if bits is not None:
+        return mask, out, bits
+    return mask, out
+
+
+def reach_any(bx, by, bz, tx, ty, tz, legs, quat=None, out=None, all_legs=None):
+    """out[l, b] = any target reachable by leg l from body b (legs used as given);
+    all_legs[b] = AND over legs."""
+    torch = _torch()
+    nb = _check_f32(bx, by, bz)
+    nt = _check_f32(tx, ty, tz)
+    legs = np.ascontiguousarray(legs, dtype=np.float32).reshape(-1, 14)
+    if out is None:
+        out = torch.empty((len(legs), nb), dtype=torch.uint8, device=bx.device)
+    if all_legs is None:
+        all_legs = torch.empty(nb, dtype=torch.uint8, device=bx.device)
+    q = _q(quat)
+    _capi.check(_capi.load().lrm_reach_any_dev(_dp(bx), _dp(by), _dp(bz), nb, _dp(tx), _dp(ty), _dp(tz), nt,
+                                               _capi._ptr(legs), len(legs), _capi._ptr(q), _dp(out),
+                                               _dp(all_legs), _stream()))
+    return out, all_legs
+
+
+def any_in_sphere(cx, cy, cz, tx, ty, tz, radius, out=None):
+    torch = _torch()
+    nc = _check_f32(cx, cy, cz)
+    nt = _check_f32(tx, ty, tz)
+    if out is None:
+        out = torch.empty(nc, dtype=torch.uint8, device=cx.device)
+    _capi.check(_capi.load().lrm_any_in_sphere_dev(_dp(cx), _dp(cy), _dp(cz), nc, _dp(tx), _dp(ty), _dp(tz), nt,
+                                                   radius, _dp(out), _stream()))
+    return out
+
+
+def any_in_cylinder(cx, cy, cz, tx, ty, tz, radius, plus_z, minus_z, out=None):
+    torch = _torch()
+    nc = _check_f32(cx, cy, cz)
+    nt = _check_f32(tx, ty, tz)
+    if out is None:
+        out = torch.empty(nc, dtype=torch.uint8, device=cx.device)
+    _capi.check(_capi.load().lrm_any_in_cylinder_dev(_dp(cx), _dp(cy), _dp(cz), nc, _dp(tx), _dp(ty), _dp(tz), nt,
+                                                     radius, plus_z, minus_z, _dp(out), _stream()))
+    return out

@@ -1,0 +1,119 @@
+"""CPU-only checks of the product library: it loads, exports every symbol include/lrm.h
+declares, its host-side leg compiler + strict per-point code (the same source the kernels
+compile) reproduce the reference fixtures bit for bit through the explicit CPU entry points
+(apply_reach_cpu / apply_dist_cpu mirrors), and the GPU entry points fail loudly, not
+silently, when there is no device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal, golden_cases, load_case, random_cloud
+
+
+def test_library_exports_every_declared_symbol(lrm):
+    declared = lrm.declared_symbols()
+    exported = set(lrm.exported_symbols())
+    assert len(declared) >= 25
+    missing = [s for s in declared if s not in exported]
+    assert not missing, missing
+
+
+def test_leg_struct_layout_and_factories(lrm):
+    legs = dict(np.load("tests/golden/legs.npz"))
+    az = legs.pop("azimuths")
+    for i, a in enumerate(az):
+        assert lrm.get_M2_leg(float(a)).tobytes() == legs[f"m2_{i}"].tobytes()
+        assert lrm.get_moonbot_leg(float(a)).tobytes() == legs[f"moonbot_{i}"].tobytes()
+    tab = np.load("tests/golden/rotate_leg_data.npy")
+    for row in tab:
+        assert lrm.rotate_leg_data(row[14:18], row[:14]).tobytes() == row[18:].tobytes()
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_cpu_entry_points_match_reference_fixture(lrm, name):
+    c = load_case(name)
+    m, ms = lrm.apply_reach_cpu(c["points"], c["leg"], c["quat"])
+    d, v, ms2 = lrm.apply_dist_cpu(c["points"], c["leg"], c["quat"])
+    assert ms >= 0 and ms2 >= 0
+    assert np.array_equal(m, c["mask"])
+    assert np.array_equal(v, c["valid"])
+    assert bits_equal(d, c["dist"]).all()
+
+
+def test_cpu_entry_points_match_oracle_on_random_cloud(lrm, oracle):
+    pts = random_cloud(200000, seed=123)
+    for leg in (lrm.get_M2_leg(0.4), lrm.get_moonbot_leg(-1.0)):
+        for q in (None, (0.97, 0.05, -0.2, 0.1)):
+            qq = (1, 0, 0, 0) if q is None else q
+            assert np.array_equal(lrm.apply_reach_cpu(pts, leg, q)[0], oracle.reach(pts, leg, qq))
+            d, v, _ = lrm.apply_dist_cpu(pts, leg, q)
+            d0, v0 = oracle.dist(pts, leg, qq)
+            assert np.array_equal(v, v0) and bits_equal(d, d0).all()
+
+
+def test_empty_and_null_arguments(lrm):
+    L = lrm.lib()
+    leg = lrm.get_M2_leg()
+    m, _ = lrm.apply_reach_cpu(np.zeros((0, 3), np.float32), leg)
+    assert m.shape == (0,)
+    # null leg -> LRM_EINVAL with a message, no crash
+    rc = L.lrm_reach_cpu(None, 4, None, None, None, None)
+    assert rc == -1 and L.lrm_last_error()
+    rc = L.lrm_reach_any_dev(None, None, None, 0, None, None, None, 0, None, 0, None, None, None, None)
+    assert rc == -1
+    assert L.lrm_set_mode(7) == -1
+    assert L.lrm_set_mode(0) == 0 and L.lrm_get_mode() == 0
+
+
+def test_gpu_entry_points_fail_loudly_without_a_device(lrm):
+    """No CPU fallback behind the GPU entry points."""
+    if lrm.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(lrm.LrmError):
+        lrm.apply_reach(np.zeros((8, 3), np.float32), lrm.get_M2_leg())
+    with pytest.raises(lrm.LrmError):
+        lrm.positionability(np.zeros((2, 3), np.float32), np.zeros((2, 3), np.float32),
+                            [lrm.get_M2_leg()], [(1, 0, 0, 0)])
+
+
+def test_exact_math_host_matches_glibc(lrm):
+    """csrc/lrm_exact_math.h (host build) == this machine's glibc atan2f / sincosf, bit for
+    bit, on the value ranges the path produces (and well beyond for atan2f)."""
+    rng = np.random.default_rng(0)
+    n = 4_000_000
+    a = np.concatenate([
+        rng.uniform(-7, 7, n).astype(np.float32),                      # angles
+        (rng.standard_normal(n) * 300).astype(np.float32),              # coordinates (mm)
+        rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32),  # any bit pattern
+        np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-38, -1e-38, np.pi, -np.pi], np.float32),
+    ])
+    b = np.concatenate([
+        (rng.standard_normal(n) * 300).astype(np.float32),
+        (rng.standard_normal(n) * 300).astype(np.float32),
+        rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32),
+        np.array([1.0, 0.0, -0.0, 0.0, np.inf, np.inf, 1.0, -1e-38, 1e38, -1.0, -1.0], np.float32),
+    ])
+    at2 = np.empty_like(a)
+    sn = np.empty_like(a)
+    cs = np.empty_like(a)
+    P = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert lrm.lib().lrm_dbg_exact_math_host(P(a), P(b), len(a), P(at2), P(sn), P(cs)) == 0
+    libm = C.CDLL("libm.so.6")
+    libm.atan2f.restype = C.c_float
+    libm.atan2f.argtypes = [C.c_float, C.c_float]
+    # vectorised libm through numpy's float32 ufuncs would go through numpy's own SIMD
+    # kernels, not glibc: call glibc directly on a subsample, and numpy on all as a second check
+    idx = rng.integers(0, len(a), 200000)
+    want = np.array([libm.atan2f(float(a[i]), float(b[i])) for i in idx], np.float32)
+    assert bits_equal(at2[idx], want).all()
+    s_ = C.c_float()
+    c_ = C.c_float()
+    libm.sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    sel = idx[np.abs(a[idx]) < 100][:100000]
+    ws = np.empty(len(sel), np.float32)
+    wc = np.empty(len(sel), np.float32)
+    for k, i in enumerate(sel):
+        libm.sincosf(float(a[i]), C.byref(s_), C.byref(c_))
+        ws[k], wc[k] = s_.value, c_.value
+    assert bits_equal(sn[sel], ws).all() and bits_equal(cs[sel], wc).all()

@@ -1,0 +1,175 @@
+"""GPU parity (run with -m gpu on an MI355X): the HIP kernels, called through the C ABI,
+against the reference fixtures, the CPU oracle, and size-independent properties at
+BASELINE.json's full sizes.  Strict mode must be BIT-IDENTICAL: mask, validity byte and every
+float of the distance field."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal, golden_cases, load_case, random_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "the gpu tests need a GPU"
+    return torch
+
+
+def soa(torch, pts):
+    t = torch.from_numpy(np.ascontiguousarray(pts.T)).cuda()
+    return t[0], t[1], t[2]
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_host_buffer_api_matches_reference_fixture(lrm, name):
+    """lrm_reach / lrm_dist / lrm_reach_dist = apply_kernel drop-ins (AoS host buffers)."""
+    c = load_case(name)
+    m, ms = lrm.apply_reach(c["points"], c["leg"], c["quat"])
+    d, v, ms2 = lrm.apply_dist(c["points"], c["leg"], c["quat"])
+    m2, d2, ms3 = lrm.apply_reach_dist(c["points"], c["leg"], c["quat"])
+    assert ms > 0 and ms2 > 0 and ms3 > 0
+    assert np.array_equal(m, c["mask"]) and np.array_equal(m2, c["mask"])
+    assert np.array_equal(v, c["valid"])
+    assert bits_equal(d, c["dist"]).all() and bits_equal(d2, c["dist"]).all()
+
+
+@pytest.mark.parametrize("name", golden_cases("cube") + golden_cases("boundary") + golden_cases("special"))
+def test_device_api_matches_reference_fixture(lrm, torch_cuda, name):
+    c = load_case(name)
+    x, y, z = soa(torch_cuda, c["points"])
+    m, bits = lrm.device.reach(x, y, z, c["leg"], c["quat"], want_bits=True)
+    d, v = lrm.device.dist(x, y, z, c["leg"], c["quat"])
+    m2, d2 = lrm.device.reach_dist(x, y, z, c["leg"], c["quat"])
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(m.cpu().numpy(), c["mask"])
+    assert np.array_equal(m2.cpu().numpy(), c["mask"])
+    assert np.array_equal(v.cpu().numpy(), c["valid"])
+    assert bits_equal(d.cpu().numpy().T, c["dist"]).all()
+    assert bits_equal(d2.cpu().numpy().T, c["dist"]).all()
+    # ballot bit mask == byte mask
+    n = len(c["mask"])
+    packed = np.packbits(np.pad(c["mask"], (0, (-n) % 64)), bitorder="little").view(np.uint64)
+    assert np.array_equal(bits.cpu().numpy().view(np.uint64), packed)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 4099, 100003])
+def test_ragged_sizes(lrm, oracle, torch_cuda, n):
+    pts = random_cloud(max(n, 1), seed=n + 1)[:n]
+    leg = lrm.get_M2_leg(0.3)
+    q = (0.98, 0.0, 0.15, 0.05)
+    want_m = oracle.reach(pts, leg, q)
+    want_d, want_v = oracle.dist(pts, leg, q)
+    if n == 0:
+        m, _ = lrm.apply_reach(pts, leg, q)
+        assert m.shape == (0,)
+        return
+    x, y, z = soa(torch_cuda, pts)
+    # guard bytes after every output: kernels must not write past n
+    mask = torch_cuda.full((n + 64,), 7, dtype=torch_cuda.uint8, device="cuda")
+    out = torch_cuda.full((3, n + 16), -777.0, dtype=torch_cuda.float32, device="cuda")
+    bits = torch_cuda.full(((n + 63) // 64 + 2,), -1, dtype=torch_cuda.int64, device="cuda")
+    lrm.device.reach(x, y, z, leg, q, out=mask[:n], bits=bits[:(n + 63) // 64])
+    ox = [out[i, :n] for i in range(3)]
+    valid = torch_cuda.full((n + 64,), 7, dtype=torch_cuda.uint8, device="cuda")
+    L = lrm.lib()
+    from lrm_amd import _capi
+    legp = np.ascontiguousarray(leg, np.float32)
+    qp = np.ascontiguousarray(q, np.float32)
+    _capi.check(L.lrm_dist_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), n, _capi._ptr(legp), _capi._ptr(qp),
+                               ox[0].data_ptr(), ox[1].data_ptr(), ox[2].data_ptr(), valid.data_ptr(),
+                               torch_cuda.cuda.current_stream().cuda_stream))
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(mask[:n].cpu().numpy(), want_m)
+    assert (mask[n:] == 7).all() and (valid[n:] == 7).all() and (out[:, n:] == -777.0).all()
+    assert (bits[(n + 63) // 64:] == -1).all()
+    assert np.array_equal(valid[:n].cpu().numpy(), want_v)
+    assert bits_equal(out[:, :n].cpu().numpy().T, want_d).all()
+    packed = np.packbits(np.pad(want_m, (0, (-n) % 64)), bitorder="little").view(np.uint64)
+    assert np.array_equal(bits[:(n + 63) // 64].cpu().numpy().view(np.uint64), packed)
+
+
+def test_random_cloud_1e6_all_legs_and_orientations(lrm, oracle, torch_cuda):
+    pts = random_cloud(1_000_000, seed=42)
+    x, y, z = soa(torch_cuda, pts)
+    for leg in (lrm.get_M2_leg(0.0), lrm.get_moonbot_leg(np.pi / 3)):
+        for q in (None, (0.924, 0, -0.384, 0), (0.9, 0.1, 0.2, -0.3)):
+            qq = (1, 0, 0, 0) if q is None else q
+            m = lrm.device.reach(x, y, z, leg, q)
+            d, v = lrm.device.dist(x, y, z, leg, q)
+            torch_cuda.cuda.synchronize()
+            assert np.array_equal(m.cpu().numpy(), oracle.reach(pts, leg, qq))
+            want_d, want_v = oracle.dist(pts, leg, qq)
+            assert np.array_equal(v.cpu().numpy(), want_v)
+            assert bits_equal(d.cpu().numpy().T, want_d).all()
+
+
+def test_full_size_config2_1e7_points(lrm, oracle, torch_cuda):
+    """BASELINE config 2 at full size: 1e7 random targets, M2 leg, identity orientation.
+    The oracle is run on the whole cloud for the mask (~1 s) and on a 2e6 slice for the
+    distance field; the rest of the field is covered by properties."""
+    n = 10_000_000
+    pts = random_cloud(n, seed=42)
+    leg = lrm.get_M2_leg(0.0)
+    x, y, z = soa(torch_cuda, pts)
+    m, bits = lrm.device.reach(x, y, z, leg, want_bits=True)
+    m2, d = lrm.device.reach_dist(x, y, z, leg)
+    torch_cuda.cuda.synchronize()
+    mask = m.cpu().numpy()
+    assert np.array_equal(mask, oracle.reach(pts, leg))
+    assert np.array_equal(m2.cpu().numpy(), mask)
+    assert 0.02 < mask.mean() < 0.08
+    # bit mask: popcount == sum of bytes, and unpacks to the bytes
+    b = bits.cpu().numpy().view(np.uint8)
+    assert np.array_equal(np.unpackbits(b, bitorder="little")[:n], mask)
+    dn = d.cpu().numpy().T
+    want_d, _ = oracle.dist(pts[:2_000_000], leg)
+    assert bits_equal(dn[:2_000_000], want_d).all()
+    # properties at full size: the field is finite; moving a point by minus its distance vector
+    # lands on the boundary of the reachable set: the residual distance there is ~0
+    assert np.isfinite(dn).all()
+    sel = np.random.default_rng(0).integers(0, n, 200000)
+    on_boundary = (pts[sel] - dn[sel]).astype(np.float32)
+    resid, _ = oracle.dist(on_boundary, leg)
+    rn = np.linalg.norm(resid, axis=1)
+    assert np.quantile(rn, 0.999) < 2e-2, np.quantile(rn, [0.5, 0.99, 0.999, 1.0])
+
+
+def test_exact_math_device_matches_host(lrm, torch_cuda):
+    """The device build of lrm_exact_math.h == its host build (itself checked against glibc
+    in the CPU suite) on angles, coordinates and raw bit patterns."""
+    rng = np.random.default_rng(1)
+    n = 2_000_000
+    a = np.concatenate([rng.uniform(-7, 7, n), rng.standard_normal(n) * 300,
+                        rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)]).astype(np.float32)
+    b = np.concatenate([rng.standard_normal(n) * 300, rng.standard_normal(n) * 300,
+                        rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)]).astype(np.float32)
+    keep = np.isfinite(a) & (np.abs(a) < 100)  # sincosf's emulated range
+    a, b = a[keep], b[keep]
+    outs = [np.empty_like(a) for _ in range(3)]
+    P = lambda v: v.ctypes.data_as(C.c_void_p)
+    assert lrm.lib().lrm_dbg_exact_math_host(P(a), P(b), len(a), *[P(o) for o in outs]) == 0
+    ta, tb = torch_cuda.from_numpy(a).cuda(), torch_cuda.from_numpy(b).cuda()
+    douts = [torch_cuda.empty_like(ta) for _ in range(3)]
+    from lrm_amd import _capi
+    _capi.check(lrm.lib().lrm_dbg_exact_math_dev(ta.data_ptr(), tb.data_ptr(), len(a), *[o.data_ptr() for o in douts],
+                                                 torch_cuda.cuda.current_stream().cuda_stream))
+    torch_cuda.cuda.synchronize()
+    for h, d_ in zip(outs, douts):
+        assert bits_equal(h, d_.cpu().numpy()).all()
+
+
+def test_device_sqrt_and_div_are_correctly_rounded(torch_cuda, lrm, oracle):
+    """The strict kernels rely on IEEE sqrtf and division on the device; a leg whose circle
+    tests sit on awkward values exercises both (bit equality with the oracle is the check)."""
+    pts = random_cloud(300000, seed=99) * np.float32(1.0000001)
+    leg = lrm.leg_factory(0.37, 150.3, -33.3, 61.7, 117.9, 142.2, 55.0, 85.0, 115.0, -7.5, -3.5)
+    x, y, z = soa(torch_cuda, pts)
+    d, v = lrm.device.dist(x, y, z, leg, (0.99, 0.02, -0.1, 0.03))
+    torch_cuda.cuda.synchronize()
+    want_d, want_v = oracle.dist(pts, leg, (0.99, 0.02, -0.1, 0.03))
+    assert np.array_equal(v.cpu().numpy(), want_v)
+    assert bits_equal(d.cpu().numpy().T, want_d).all()

@@ -1,0 +1,104 @@
+"""GPU parity of the body x target aggregation (reach_mem_kernel semantics,
+several_leg.cu:92-192) and of the collision any-reductions (collision.cu:40-146) against a
+brute-force composition of the single-leg oracle.  several_leg.cu is not compiled by the
+reference's own build and cannot run here: the sweep semantics are restated from its source
+and pinned only through the (reference-pinned) single-leg reachability they compose."""
+import numpy as np
+import pytest
+
+from conftest import random_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def soa(torch, pts):
+    t = torch.from_numpy(np.ascontiguousarray(pts.T)).cuda()
+    return t[0], t[1], t[2]
+
+
+def scene(nb, nt, seed):
+    rng = np.random.default_rng(seed)
+    # rough terrain patch and bodies hovering 100-300 mm above it
+    txy = rng.uniform(-900, 900, (nt, 2))
+    tz = 40 * np.sin(txy[:, 0] / 150) + 30 * np.cos(txy[:, 1] / 110) + rng.normal(0, 5, nt)
+    targets = np.column_stack([txy, tz]).astype(np.float32)
+    bxy = rng.uniform(-700, 700, (nb, 2))
+    bz = rng.uniform(60, 330, nb)
+    bodies = np.column_stack([bxy, bz]).astype(np.float32)
+    return bodies, targets
+
+
+@pytest.mark.parametrize("nlegs,quat", [(4, (1, 0, 0, 0)), (6, (1, 0, 0, 0)), (6, (0.98, 0.05, -0.12, 0.1)), (1, (0.9, 0, 0.3, 0))])
+def test_reach_any_matches_bruteforce_oracle(lrm, oracle, torch_cuda, nlegs, quat):
+    bodies, targets = scene(333, 5003, seed=nlegs)
+    legs = np.stack([lrm.rotate_leg_data(quat, lrm.get_M2_leg(2 * np.pi * k / nlegs)) for k in range(nlegs)])
+    want = oracle.reach_any(bodies, targets, legs, quat)
+    bx, by, bz = soa(torch_cuda, bodies)
+    tx, ty, tz = soa(torch_cuda, targets)
+    out, all_legs = lrm.device.reach_any(bx, by, bz, tx, ty, tz, legs, quat)
+    torch_cuda.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert 0.02 < want.mean() < 0.98  # both outcomes exercised
+    assert np.array_equal(all_legs.cpu().numpy(), want.min(axis=0))
+
+
+def test_reach_any_edge_cases(lrm, oracle, torch_cuda):
+    bodies, targets = scene(17, 70, seed=5)
+    legs = np.stack([lrm.get_moonbot_leg(k * np.pi / 2) for k in range(4)])
+    bx, by, bz = soa(torch_cuda, bodies)
+    tx, ty, tz = soa(torch_cuda, targets)
+    # no targets at all -> nothing reachable, output fully written
+    e = torch_cuda.empty(0, dtype=torch_cuda.float32, device="cuda")
+    out, al = lrm.device.reach_any(bx, by, bz, e, e, e, legs)
+    torch_cuda.cuda.synchronize()
+    assert (out == 0).all() and (al == 0).all()
+    # a single target / a single body
+    out, _ = lrm.device.reach_any(bx, by, bz, tx[:1].clone(), ty[:1].clone(), tz[:1].clone(), legs)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.reach_any(bodies, targets[:1], legs))
+    out, _ = lrm.device.reach_any(bx[:1].clone(), by[:1].clone(), bz[:1].clone(), tx, ty, tz, legs)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.reach_any(bodies[:1], targets, legs))
+
+
+def test_positionability_sweep_matches_bruteforce(lrm, oracle, torch_cuda):
+    """lrm_positionability (host buffers): OR over orientations of AND over legs, with bodies
+    and targets rotated by each quaternion and leg limits rotated per orientation."""
+    bodies, targets = scene(150, 3000, seed=9)
+    legs = np.stack([lrm.get_M2_leg(k * np.pi / 3) for k in range(6)])
+    quats = [oracle.quat_from_vect_angle((0, 0, 1), 0.0), oracle.quat_from_vect_angle((0, 1, 0), np.pi / 8)]
+    quats.append(oracle.qt_multiply(oracle.quat_from_vect_angle((0, 0, 1), np.pi / 4), quats[1]))
+    got, ms = lrm.positionability(bodies, targets, legs, quats)
+    want = np.zeros(len(bodies), np.uint8)
+    for q in quats:
+        rb = np.stack([oracle.qt_rotate(q, b) for b in bodies])
+        rt = np.stack([oracle.qt_rotate(q, t) for t in targets])
+        rl = np.stack([oracle.rotate_leg_data(q, l) for l in legs])
+        want |= oracle.reach_any(rb, rt, rl, q).min(axis=0)
+    assert ms > 0
+    assert np.array_equal(got, want)
+
+
+def test_any_in_sphere_and_cylinder(lrm, oracle, torch_cuda):
+    bodies, targets = scene(700, 2500, seed=21)
+    bx, by, bz = soa(torch_cuda, bodies)
+    tx, ty, tz = soa(torch_cuda, targets)
+    s = lrm.device.any_in_sphere(bx, by, bz, tx, ty, tz, 120.0)
+    c = lrm.device.any_in_cylinder(bx, by, bz, tx, ty, tz, 181.0, 250.0, -110.0)
+    torch_cuda.cuda.synchronize()
+    d = bodies[:, None, :].astype(np.float32) - targets[None, :, :]
+    # restate with the same float32 operation order as collision.cu.h:5-23
+    ws = (np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]) < np.float32(120.0)).any(1)
+    dz = -d[..., 2]
+    wc = ((np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) < np.float32(181.0)) & (dz < 250.0) & (dz > -110.0)).any(1)
+    assert np.array_equal(s.cpu().numpy().astype(bool), ws)
+    assert np.array_equal(c.cpu().numpy().astype(bool), wc)
+    assert 0 < ws.mean() < 1 and 0 < wc.mean() < 1
