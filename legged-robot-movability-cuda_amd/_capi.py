@@ -45,6 +45,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise LrmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the HIP path)")
+    try:
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7; importing it
+        # first makes liblrm.so bind to that copy, so torch's device pointers and streams are
+        # valid in our launches.  Without torch the library binds to /opt/rocm's runtime.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, fp = C.c_void_p, C.c_size_t, C.c_float
     L.lrm_version.restype = C.c_char_p
