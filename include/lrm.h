@@ -100,8 +100,9 @@ int lrm_dist_cpu(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, co
 /* ---- device-resident entry points (no allocation, no copy, no sync) --------------------
  * Pointers are device pointers; coordinates are SoA (one f32 array per component: the same
  * layout the reference keeps on disk, several_leg.cpp:126-131).  `stream` is a hipStream_t
- * (NULL = default stream).  `n` need not be a multiple of anything; arrays must be 16-byte
- * aligned (hipMalloc / torch allocations are).  Launch only: the caller synchronises. */
+ * (NULL = default stream).  `n` need not be a multiple of anything; 16-byte aligned arrays
+ * (hipMalloc / torch allocations are) take the vectorised kernels, anything else a scalar
+ * variant with identical results.  Launch only: the caller synchronises. */
 int lrm_reach_dev(const float* x, const float* y, const float* z, size_t n,
                   const LrmLegDimensions* leg, const float* quat, uint8_t* mask, void* stream);
 /* as lrm_reach_dev, plus a wave-ballot bit mask: bit (i & 63) of bits[i >> 6]

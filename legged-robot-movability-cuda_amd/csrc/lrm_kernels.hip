@@ -86,6 +86,31 @@ __global__ __launch_bounds__(kBlock) void reach_soa_kernel(const float* __restri
     }
 }
 
+// Same computation, one point per lane: used when the arrays are not 16-byte aligned (views
+// into a larger allocation).  The wave ballot is the bit word.
+__global__ __launch_bounds__(kBlock) void reach_soa_scalar_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ y,
+                                                                  const float* __restrict__ z, size_t n,
+                                                                  const LrmCompiledLeg L,
+                                                                  uint8_t* __restrict__ mask,
+                                                                  uint64_t* __restrict__ bits) {
+    __shared__ LrmCircle s_lists[16];
+    stage_lists(L, s_lists);
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const size_t n_pad = (n + 63) & ~(size_t)63;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
+        bool m = false;
+        if (i < n) {
+            m = lrm_reach_global(L, s_lists, LrmVec3{x[i], y[i], z[i]});
+            if (mask) mask[i] = m;
+        }
+        if (bits) {
+            const uint64_t w = __ballot(m);
+            if ((threadIdx.x & 63) == 0) bits[i >> 6] = w;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // distance_global_kernel (one_leg_global.cu:157-166) and the fused reach+distance kernel:
 // one point per lane per iteration (the distance code is long: keep one copy of it).
@@ -331,6 +356,11 @@ hipError_t lrm_launch_warmup(size_t n, hipStream_t st) {
 
 hipError_t lrm_launch_reach_soa(const float* x, const float* y, const float* z, size_t n,
                                 const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, hipStream_t st) {
+    const uintptr_t align = (uintptr_t)x | (uintptr_t)y | (uintptr_t)z;
+    if ((align & 15) || ((uintptr_t)mask & 3)) {
+        hipLaunchKernelGGL(reach_soa_scalar_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
+        return hipGetLastError();
+    }
     const int grid = grid_for((n + 3) / 4);
     if (bits) hipLaunchKernelGGL(reach_soa_kernel<true>, dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
     else hipLaunchKernelGGL(reach_soa_kernel<false>, dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);

@@ -24,8 +24,6 @@ def _check_f32(*ts):
     for t in ts:
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
             raise ValueError("expected contiguous float32 CUDA tensors of equal length")
-        if t.data_ptr() % 16:
-            raise ValueError("coordinate arrays must be 16-byte aligned")
     return n
 
 
