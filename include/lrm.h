@@ -165,6 +165,13 @@ int lrm_dbg_exact_math_host(const float* a, const float* b, size_t n, float* at2
 int lrm_dbg_exact_math_dev(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs,
                            void* stream);
 
+/* The filtered (LRM_MODE_FAST) per-point evaluation run on the host WITHOUT its strict
+ * fallback, plus the per-point "uncertain" flags that would trigger the fallback.  Any output
+ * pointer may be NULL.  Fails with LRM_EINVAL for a leg the filter does not support. */
+int lrm_dbg_fast_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+                      uint8_t* mask_out, uint8_t* mask_uncertain_out, float* dxyz_aos_out,
+                      uint8_t* valid_out, uint8_t* dist_uncertain_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,7 @@ def load():
         "lrm_dist_aos_dev": [vp, sz, vp, vp, vp, vp, vp],
         "lrm_reach_any_dev": [vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp],
         "lrm_positionability": [vp, sz, vp, sz, vp, sz, vp, sz, vp, vp],
+        "lrm_dbg_fast_host": [vp, sz, vp, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
         "lrm_dbg_exact_math_dev": [vp, vp, sz, vp, vp, vp, vp],
         "lrm_any_in_sphere_dev": [vp, vp, vp, sz, vp, vp, vp, sz, fp, vp, vp],
@@ -204,6 +205,18 @@ def apply_dist_cpu(xyz, leg, quat=None):
     check(load().lrm_dist_cpu(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(d), _ptr(v),
                               C.addressof(ms)))
     return d, v, ms.value
+
+
+def dbg_fast_host(xyz, leg, quat=None):
+    """Filtered evaluation on the host without fallback -> dict(mask, mask_unc, dist, valid, dist_unc)."""
+    xyz = _f32(xyz, (-1, 3))
+    n = len(xyz)
+    out = dict(mask=np.zeros(n, np.uint8), mask_unc=np.zeros(n, np.uint8), dist=np.zeros_like(xyz),
+               valid=np.zeros(n, np.uint8), dist_unc=np.zeros(n, np.uint8))
+    check(load().lrm_dbg_fast_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(out["mask"]),
+                                   _ptr(out["mask_unc"]), _ptr(out["dist"]), _ptr(out["valid"]),
+                                   _ptr(out["dist_unc"])))
+    return out
 
 
 def positionability(bodies, targets, legs, quats):

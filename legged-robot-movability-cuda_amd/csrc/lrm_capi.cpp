@@ -9,6 +9,7 @@
 #include "lrm_compile.h"
 #include "lrm_launch.h"
 #include "lrm_point.h"
+#include "lrm_point_fast.h"
 
 namespace {
 
@@ -73,9 +74,9 @@ int host_apply(int op, const float* xyz, size_t n, const LrmLegDimensions* leg, 
     HIP_TRY(hipEventCreate(&ev.b), "hipEventCreate");
     HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
     if (n) {
-        if (op == 0) HIP_TRY(lrm_launch_reach_aos(d_in.as<float>(), n, L, d_mask.as<uint8_t>(), nullptr), "Kernel launch");
+        if (op == 0) HIP_TRY(lrm_launch_reach_aos(d_in.as<float>(), n, L, d_mask.as<uint8_t>(), g_mode == LRM_MODE_FAST, nullptr), "Kernel launch");
         else HIP_TRY(lrm_launch_dist_aos(op, d_in.as<float>(), n, L, want_mask ? d_mask.as<uint8_t>() : nullptr,
-                                         d_out.as<float>(), nullptr), "Kernel launch");
+                                         d_out.as<float>(), g_mode == LRM_MODE_FAST, nullptr), "Kernel launch");
     }
     HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
     HIP_TRY(hipEventSynchronize(ev.b), "Kernel launch");
@@ -179,7 +180,7 @@ int lrm_reach_bits_dev(const float* x, const float* y, const float* z, size_t n,
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_reach_soa(x, y, z, n, L, mask, bits, (hipStream_t)stream), "reach launch");
+    HIP_TRY(lrm_launch_reach_soa(x, y, z, n, L, mask, bits, g_mode == LRM_MODE_FAST, (hipStream_t)stream), "reach launch");
     return LRM_OK;
 }
 int lrm_reach_dev(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
@@ -192,7 +193,7 @@ int lrm_dist_dev(const float* x, const float* y, const float* z, size_t n, const
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_dist_soa(1, x, y, z, n, L, valid, nullptr, dx, dy, dz, (hipStream_t)stream), "dist launch");
+    HIP_TRY(lrm_launch_dist_soa(1, x, y, z, n, L, valid, nullptr, dx, dy, dz, g_mode == LRM_MODE_FAST, (hipStream_t)stream), "dist launch");
     return LRM_OK;
 }
 int lrm_reach_dist_bits_dev(const float* x, const float* y, const float* z, size_t n,
@@ -203,7 +204,7 @@ int lrm_reach_dist_bits_dev(const float* x, const float* y, const float* z, size
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_dist_soa(2, x, y, z, n, L, mask, bits, dx, dy, dz, (hipStream_t)stream), "reach+dist launch");
+    HIP_TRY(lrm_launch_dist_soa(2, x, y, z, n, L, mask, bits, dx, dy, dz, g_mode == LRM_MODE_FAST, (hipStream_t)stream), "reach+dist launch");
     return LRM_OK;
 }
 int lrm_reach_dist_dev(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
@@ -217,7 +218,7 @@ int lrm_reach_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, c
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_reach_aos(xyz, n, L, mask, (hipStream_t)stream), "reach launch");
+    HIP_TRY(lrm_launch_reach_aos(xyz, n, L, mask, g_mode == LRM_MODE_FAST, (hipStream_t)stream), "reach launch");
     return LRM_OK;
 }
 int lrm_dist_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, float* dxyz,
@@ -226,7 +227,7 @@ int lrm_dist_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, co
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_dist_aos(1, xyz, n, L, valid, dxyz, (hipStream_t)stream), "dist launch");
+    HIP_TRY(lrm_launch_dist_aos(1, xyz, n, L, valid, dxyz, g_mode == LRM_MODE_FAST, (hipStream_t)stream), "dist launch");
     return LRM_OK;
 }
 
@@ -269,8 +270,10 @@ int lrm_reach_any_dev(const float* bx, const float* by, const float* bz, size_t 
     HIP_TRY(hipMemcpyAsync(dev_legs, host_legs, sizeof(LrmCompiledLeg) * nlegs, hipMemcpyHostToDevice,
                            (hipStream_t)stream), "hipMemcpyAsync legs");
     // pageable-source async copies are staged by the runtime before returning, so host_legs may die
+    bool fast = g_mode == LRM_MODE_FAST;
+    for (size_t l = 0; l < nlegs; l++) fast = fast && host_legs[l].fast_ok;
     HIP_TRY(lrm_launch_reach_any(bx, by, bz, nb, tx, ty, tz, nt, dev_legs, (int)nlegs, out_leg_body, all_legs_out,
-                                 (hipStream_t)stream), "reach_any launch");
+                                 fast, (hipStream_t)stream), "reach_any launch");
     return LRM_OK;
 }
 
@@ -306,6 +309,37 @@ int lrm_dbg_exact_math_dev(const float* a, const float* b, size_t n, float* at2,
     if (n && (!a || !b || !at2 || !sn || !cs)) return fail(LRM_EINVAL, "null argument");
     if (n == 0) return LRM_OK;
     HIP_TRY(lrm_launch_exact_math(a, b, n, at2, sn, cs, (hipStream_t)stream), "exact_math launch");
+    return LRM_OK;
+}
+
+// The filtered evaluation (lrm_point_fast.h) on the host, WITHOUT the strict fallback, with its
+// `uncertain` flags: tests check that every point not flagged equals the strict result and
+// count how many are flagged.  Outputs may be NULL.
+int lrm_dbg_fast_host(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat,
+                      uint8_t* mask_out, uint8_t* mask_unc_out, float* dxyz_out, uint8_t* valid_out,
+                      uint8_t* dist_unc_out) {
+    if (!leg || (n && !xyz)) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    if (!L.fast_ok) return fail(LRM_EINVAL, "leg not eligible for the filtered evaluation");
+    for (size_t i = 0; i < n; i++) {
+        const LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        if (mask_out) {
+            uint32_t unc = 0;
+            mask_out[i] = lrm_reach_global_fast(L, &L.lists[0][0], &L.flists[0][0], p, unc);
+            if (mask_unc_out) mask_unc_out[i] = (uint8_t)unc;
+        }
+        if (dxyz_out) {
+            uint32_t unc = 0;
+            LrmVec3 d = p;
+            const bool v = lrm_dist_global_fast(L, &L.lists[0][0], &L.flists[0][0], d, unc);
+            dxyz_out[3 * i] = d.x;
+            dxyz_out[3 * i + 1] = d.y;
+            dxyz_out[3 * i + 2] = d.z;
+            if (valid_out) valid_out[i] = v;
+            if (dist_unc_out) dist_unc_out[i] = (uint8_t)unc;
+        }
+    }
     return LRM_OK;
 }
 

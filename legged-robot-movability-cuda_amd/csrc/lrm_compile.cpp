@@ -207,6 +207,58 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
     out->full_sat[0] = side_flags(l, false).full_sat;
     out->full_sat[1] = side_flags(l, true).full_sat;
 
+    // ---- filtered-evaluation constants (double precision on the host, rounded once) ----
+    const double margin = 0.001;
+    double scale = 0;
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < LRM_N_CIRCLES; i++) {
+            const LrmCircle& ci = out->lists[k][i];
+            auto& f = out->flists[k][i];
+            const double r = ci.r;
+            if (ci.attract != 0.f) {
+                f.T = (float)((r + margin) * (r + margin));
+                f.sg = 1.f;
+            } else {
+                const double lo = r - margin;
+                f.T = (lo > 0) ? (float)(lo * lo) : -1.f; // r <= margin: always valid (m > -1)
+                f.sg = -1.f;
+            }
+            f.g = (float)(2 * (r + margin));
+            f.pad = 0.f;
+            const double sc = std::fabs((double)ci.x) + std::fabs((double)ci.y) + r;
+            if (sc > scale) scale = sc;
+        }
+    out->fast_scale = (float)scale;
+    const float dirs[5] = {out->region_mid, out->full_sat[0], out->full_sat[1], out->max_coxa, out->min_coxa};
+    for (int i = 0; i < 5; i++) {
+        out->dir_cos[i] = (float)std::cos((double)dirs[i]);
+        out->dir_sin[i] = (float)std::sin((double)dirs[i]);
+    }
+    // The cross-product form of the coxa range test needs both limits well inside
+    // (-pi/2, pi/2) (the yaw is measured on the point mirrored into x >= 0); the region
+    // constants must be finite and away from +-pi.  Anything else: strict path.
+    const double half_pi = 1.5707963267948966, pi = 3.141592653589793;
+    bool ok = std::isfinite(scale) && scale > 0 && scale < 2000.0; // own-circle clamp validity needs 4u*r << margin
+    ok = ok && std::fabs((double)out->max_coxa) < half_pi - 1e-3 && std::fabs((double)out->min_coxa) < half_pi - 1e-3;
+    ok = ok && out->min_coxa < out->max_coxa;
+    for (int i = 0; i < 3; i++) ok = ok && std::isfinite(dirs[i]) && std::fabs((double)dirs[i]) < pi - 1e-3;
+    for (int k = 0; k < 4 && ok; k++)
+        for (int i = 0; i < LRM_N_CIRCLES; i++) ok = ok && out->lists[k][i].r > 0.01f; // no degenerate circle
+    out->fast_ok = ok ? 1 : 0;
+    // corner points without bit-identical repeats (the reference lists one configuration twice,
+    // circles.cu.h:447-450; a repeat can never win the "strictly closer" test of one_leg.cu:135)
+    out->n_ucorners = 0;
+    for (int i = 0; i < out->n_corners; i++) {
+        bool dup = false;
+        for (int j = 0; j < out->n_ucorners; j++)
+            dup = dup || (out->ucorner_x[j] == out->corner_x[i] && out->ucorner_y[j] == out->corner_y[i]);
+        if (!dup) {
+            out->ucorner_x[out->n_ucorners] = out->corner_x[i];
+            out->ucorner_y[out->n_ucorners] = out->corner_y[i];
+            out->n_ucorners++;
+        }
+    }
+
     // Nothing farther than the stretched leg (+1 mm and 1e-4 relative slack, three orders of
     // magnitude above the float rounding of the strict evaluation) can pass the attractive
     // circle test, so pairs beyond this radius are skipped without changing any result.

@@ -14,32 +14,59 @@
 #include <stdint.h>
 #include "lrm_launch.h"
 #include "lrm_point.h"
+#include "lrm_point_fast.h"
 
 namespace {
 
 constexpr int kBlock = 256;
 
-__device__ __forceinline__ void stage_lists(const LrmCompiledLeg& L, LrmCircle* s_lists) {
-    // 16 circles x 4 floats; one float per thread
+// LDS image of the per-lane-indexed tables: 16 circles + their 16 filter records (512 B)
+struct LdsTables {
+    LrmCircle lists[16];
+    LrmCompiledLeg::FastCircle flists[16];
+};
+
+__device__ __forceinline__ void stage_lists(const LrmCompiledLeg& L, LdsTables* t) {
+    // 2 x 64 floats; one float of each table per thread of the first wave
     const float* src = reinterpret_cast<const float*>(&L.lists[0][0]);
-    float* dst = reinterpret_cast<float*>(s_lists);
-    if (threadIdx.x < 64) dst[threadIdx.x] = src[threadIdx.x];
+    const float* fsrc = reinterpret_cast<const float*>(&L.flists[0][0]);
+    if (threadIdx.x < 64) {
+        reinterpret_cast<float*>(t->lists)[threadIdx.x] = src[threadIdx.x];
+        reinterpret_cast<float*>(t->flists)[threadIdx.x] = fsrc[threadIdx.x];
+    }
     __syncthreads();
+}
+
+// mode dispatch: kFast selects the filtered evaluation (bit-identical, see lrm_point_fast.h)
+template <bool kFast>
+__device__ __forceinline__ bool eval_reach(const LrmCompiledLeg& L, const LdsTables* t, LrmVec3 p) {
+    if (kFast) return lrm_reach_global_filtered(L, t->lists, t->flists, p);
+    return lrm_reach_global(L, t->lists, p);
+}
+template <bool kFast>
+__device__ __forceinline__ bool eval_dist(const LrmCompiledLeg& L, const LdsTables* t, LrmVec3& p) {
+    if (kFast) return lrm_dist_global_filtered(L, t->lists, t->flists, p);
+    return lrm_dist_global(L, t->lists, p);
+}
+template <bool kFast>
+__device__ __forceinline__ bool eval_pair(const LrmCompiledLeg& L, const LdsTables* t, LrmVec3 tg, LrmVec3 body) {
+    if (kFast) return lrm_reachable_rotate_leg_filtered(L, t->lists, t->flists, tg, body);
+    return lrm_reachable_rotate_leg(L, t->lists, tg, body);
 }
 
 // ------------------------------------------------------------------------------------
 // reachability_global_kernel (one_leg_global.cu:149-156), 4 consecutive points per lane:
 // three 16-byte loads in, one 4-byte store out.
 // ------------------------------------------------------------------------------------
-template <bool kBits>
+template <bool kBits, bool kFast>
 __global__ __launch_bounds__(kBlock) void reach_soa_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ y,
                                                            const float* __restrict__ z, size_t n,
                                                            const LrmCompiledLeg L,
                                                            uint8_t* __restrict__ mask,
                                                            uint64_t* __restrict__ bits) {
-    __shared__ LrmCircle s_lists[16];
-    stage_lists(L, s_lists);
+    __shared__ LdsTables s_tab;
+    stage_lists(L, &s_tab);
     const size_t nquad = n >> 2;
     // every wave runs the same number of iterations so that the shuffles below see all lanes
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -50,10 +77,10 @@ __global__ __launch_bounds__(kBlock) void reach_soa_kernel(const float* __restri
             const float4 vx = reinterpret_cast<const float4*>(x)[qd];
             const float4 vy = reinterpret_cast<const float4*>(y)[qd];
             const float4 vz = reinterpret_cast<const float4*>(z)[qd];
-            const bool r0 = lrm_reach_global(L, s_lists, LrmVec3{vx.x, vy.x, vz.x});
-            const bool r1 = lrm_reach_global(L, s_lists, LrmVec3{vx.y, vy.y, vz.y});
-            const bool r2 = lrm_reach_global(L, s_lists, LrmVec3{vx.z, vy.z, vz.z});
-            const bool r3 = lrm_reach_global(L, s_lists, LrmVec3{vx.w, vy.w, vz.w});
+            const bool r0 = eval_reach<kFast>(L, &s_tab, LrmVec3{vx.x, vy.x, vz.x});
+            const bool r1 = eval_reach<kFast>(L, &s_tab, LrmVec3{vx.y, vy.y, vz.y});
+            const bool r2 = eval_reach<kFast>(L, &s_tab, LrmVec3{vx.z, vy.z, vz.z});
+            const bool r3 = eval_reach<kFast>(L, &s_tab, LrmVec3{vx.w, vy.w, vz.w});
             packed = (uint32_t)r0 | ((uint32_t)r1 << 8) | ((uint32_t)r2 << 16) | ((uint32_t)r3 << 24);
             if (mask) reinterpret_cast<uint32_t*>(mask)[qd] = packed;
         }
@@ -73,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void reach_soa_kernel(const float* __restri
     const size_t tail0 = nquad << 2;
     if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
         const size_t i = tail0 + threadIdx.x;
-        const bool r = lrm_reach_global(L, s_lists, LrmVec3{x[i], y[i], z[i]});
+        const bool r = eval_reach<kFast>(L, &s_tab, LrmVec3{x[i], y[i], z[i]});
         if (mask) mask[i] = r;
     }
     if (kBits && blockIdx.x == 0 && threadIdx.x == 0 && (n & 63)) {
@@ -81,27 +108,28 @@ __global__ __launch_bounds__(kBlock) void reach_soa_kernel(const float* __restri
         const size_t w0 = n & ~(size_t)63;
         uint64_t w = 0;
         for (size_t i = w0; i < n; i++)
-            w |= (uint64_t)lrm_reach_global(L, s_lists, LrmVec3{x[i], y[i], z[i]}) << (i - w0);
+            w |= (uint64_t)eval_reach<kFast>(L, &s_tab, LrmVec3{x[i], y[i], z[i]}) << (i - w0);
         bits[w0 >> 6] = w;
     }
 }
 
 // Same computation, one point per lane: used when the arrays are not 16-byte aligned (views
 // into a larger allocation).  The wave ballot is the bit word.
+template <bool kFast>
 __global__ __launch_bounds__(kBlock) void reach_soa_scalar_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ y,
                                                                   const float* __restrict__ z, size_t n,
                                                                   const LrmCompiledLeg L,
                                                                   uint8_t* __restrict__ mask,
                                                                   uint64_t* __restrict__ bits) {
-    __shared__ LrmCircle s_lists[16];
-    stage_lists(L, s_lists);
+    __shared__ LdsTables s_tab;
+    stage_lists(L, &s_tab);
     const size_t stride = (size_t)gridDim.x * kBlock;
     const size_t n_pad = (n + 63) & ~(size_t)63;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
         bool m = false;
         if (i < n) {
-            m = lrm_reach_global(L, s_lists, LrmVec3{x[i], y[i], z[i]});
+            m = eval_reach<kFast>(L, &s_tab, LrmVec3{x[i], y[i], z[i]});
             if (mask) mask[i] = m;
         }
         if (bits) {
@@ -116,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void reach_soa_scalar_kernel(const float* _
 // one point per lane per iteration (the distance code is long: keep one copy of it).
 // kOp: 1 = distance (+ optional validity byte), 2 = reach mask + distance.
 // ------------------------------------------------------------------------------------
-template <int kOp>
+template <int kOp, bool kFast>
 __global__ __launch_bounds__(kBlock) void dist_soa_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ y,
                                                           const float* __restrict__ z, size_t n,
@@ -126,16 +154,16 @@ __global__ __launch_bounds__(kBlock) void dist_soa_kernel(const float* __restric
                                                           float* __restrict__ dx,
                                                           float* __restrict__ dy,
                                                           float* __restrict__ dz) {
-    __shared__ LrmCircle s_lists[16];
-    stage_lists(L, s_lists);
+    __shared__ LdsTables s_tab;
+    stage_lists(L, &s_tab);
     const size_t stride = (size_t)gridDim.x * kBlock;
     const size_t n_pad = (n + 63) & ~(size_t)63; // whole waves iterate together (ballot below)
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
         bool m = false;
         if (i < n) {
             LrmVec3 p{x[i], y[i], z[i]};
-            if (kOp == 2) m = lrm_reach_global(L, s_lists, p);
-            const bool v = lrm_dist_global(L, s_lists, p);
+            if (kOp == 2) m = eval_reach<kFast>(L, &s_tab, p);
+            const bool v = eval_dist<kFast>(L, &s_tab, p);
             dx[i] = p.x;
             dy[i] = p.y;
             dz[i] = p.z;
@@ -150,31 +178,32 @@ __global__ __launch_bounds__(kBlock) void dist_soa_kernel(const float* __restric
 }
 
 // AoS variants for the apply_kernel boundary (cross_compiled.cu:33-79)
+template <bool kFast>
 __global__ __launch_bounds__(kBlock) void reach_aos_kernel(const float* __restrict__ xyz, size_t n,
                                                            const LrmCompiledLeg L,
                                                            uint8_t* __restrict__ mask) {
-    __shared__ LrmCircle s_lists[16];
-    stage_lists(L, s_lists);
+    __shared__ LdsTables s_tab;
+    stage_lists(L, &s_tab);
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-        mask[i] = lrm_reach_global(L, s_lists, p);
+        mask[i] = eval_reach<kFast>(L, &s_tab, p);
     }
 }
 
-template <int kOp>
+template <int kOp, bool kFast>
 __global__ __launch_bounds__(kBlock) void dist_aos_kernel(const float* __restrict__ xyz, size_t n,
                                                           const LrmCompiledLeg L,
                                                           uint8_t* __restrict__ mask,
                                                           float* __restrict__ dxyz) {
-    __shared__ LrmCircle s_lists[16];
-    stage_lists(L, s_lists);
+    __shared__ LdsTables s_tab;
+    stage_lists(L, &s_tab);
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         bool m = false;
-        if (kOp == 2) m = lrm_reach_global(L, s_lists, p);
-        const bool v = lrm_dist_global(L, s_lists, p);
+        if (kOp == 2) m = eval_reach<kFast>(L, &s_tab, p);
+        const bool v = eval_dist<kFast>(L, &s_tab, p);
         dxyz[3 * i] = p.x;
         dxyz[3 * i + 1] = p.y;
         dxyz[3 * i + 2] = p.z;
@@ -202,16 +231,17 @@ constexpr int kBodiesPerWave = 4;
 constexpr int kBodiesPerBlock = kWaves * kBodiesPerWave;
 constexpr int kTargetTile = 1024;
 
+template <bool kFast>
 __global__ __launch_bounds__(kBlock) void reach_any_kernel(
     const float* __restrict__ bx, const float* __restrict__ by, const float* __restrict__ bz, size_t nb,
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, size_t nt,
     const LrmCompiledLeg* __restrict__ legs, uint8_t* __restrict__ out) {
-    __shared__ LrmCircle s_lists[16];
+    __shared__ LdsTables s_tab;
     __shared__ float s_tx[kTargetTile], s_ty[kTargetTile], s_tz[kTargetTile];
     __shared__ int s_todo; // waves of this block that still have an unsatisfied body
 
     const LrmCompiledLeg& L = legs[blockIdx.y];
-    stage_lists(L, s_lists);
+    stage_lists(L, &s_tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t body0 = (size_t)blockIdx.x * kBodiesPerBlock + (size_t)wave * kBodiesPerWave;
 
@@ -246,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
                     const LrmVec3 t{s_tx[i], s_ty[i], s_tz[i]};
                     const float ddx = t.x - body[k].x, ddy = t.y - body[k].y, ddz = t.z - body[k].z;
                     const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-                    if (d2 <= r2max) hit = lrm_reachable_rotate_leg(L, s_lists, t, body[k]);
+                    if (d2 <= r2max) hit = eval_pair<kFast>(L, &s_tab, t, body[k]);
                 }
                 if (__ballot(hit) != 0ull) {
                     found[k] = true;
@@ -355,45 +385,57 @@ hipError_t lrm_launch_warmup(size_t n, hipStream_t st) {
 }
 
 hipError_t lrm_launch_reach_soa(const float* x, const float* y, const float* z, size_t n,
-                                const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, hipStream_t st) {
+                                const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, bool fast, hipStream_t st) {
+    fast = fast && L.fast_ok;
     const uintptr_t align = (uintptr_t)x | (uintptr_t)y | (uintptr_t)z;
     if ((align & 15) || ((uintptr_t)mask & 3)) {
-        hipLaunchKernelGGL(reach_soa_scalar_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
+        if (fast) hipLaunchKernelGGL(reach_soa_scalar_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
+        else hipLaunchKernelGGL(reach_soa_scalar_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
         return hipGetLastError();
     }
     const int grid = grid_for((n + 3) / 4);
-    if (bits) hipLaunchKernelGGL(reach_soa_kernel<true>, dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
-    else hipLaunchKernelGGL(reach_soa_kernel<false>, dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
+    if (bits && fast) hipLaunchKernelGGL((reach_soa_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
+    else if (bits) hipLaunchKernelGGL((reach_soa_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
+    else if (fast) hipLaunchKernelGGL((reach_soa_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
+    else hipLaunchKernelGGL((reach_soa_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
     return hipGetLastError();
 }
 
 hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const float* z, size_t n,
                                const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
-                               float* dz, hipStream_t st) {
+                               float* dz, bool fast, hipStream_t st) {
+    fast = fast && L.fast_ok;
     const int grid = grid_for(n);
-    if (op == 2) hipLaunchKernelGGL(dist_soa_kernel<2>, dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
-    else hipLaunchKernelGGL(dist_soa_kernel<1>, dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
+    if (op == 2 && fast) hipLaunchKernelGGL((dist_soa_kernel<2, true>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
+    else if (op == 2) hipLaunchKernelGGL((dist_soa_kernel<2, false>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
+    else if (fast) hipLaunchKernelGGL((dist_soa_kernel<1, true>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
+    else hipLaunchKernelGGL((dist_soa_kernel<1, false>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
     return hipGetLastError();
 }
 
-hipError_t lrm_launch_reach_aos(const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask, hipStream_t st) {
-    hipLaunchKernelGGL(reach_aos_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask);
+hipError_t lrm_launch_reach_aos(const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask, bool fast,
+                                hipStream_t st) {
+    if (fast && L.fast_ok) hipLaunchKernelGGL(reach_aos_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask);
+    else hipLaunchKernelGGL(reach_aos_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask);
     return hipGetLastError();
 }
 
 hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask,
-                               float* dxyz, hipStream_t st) {
-    if (op == 2) hipLaunchKernelGGL(dist_aos_kernel<2>, dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask, dxyz);
-    else hipLaunchKernelGGL(dist_aos_kernel<1>, dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask, dxyz);
+                               float* dxyz, bool fast, hipStream_t st) {
+    fast = fast && L.fast_ok;
+    if (op == 2 && fast) hipLaunchKernelGGL((dist_aos_kernel<2, true>), dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask, dxyz);
+    else if (op == 2) hipLaunchKernelGGL((dist_aos_kernel<2, false>), dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask, dxyz);
+    else if (fast) hipLaunchKernelGGL((dist_aos_kernel<1, true>), dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask, dxyz);
+    else hipLaunchKernelGGL((dist_aos_kernel<1, false>), dim3(grid_for(n)), dim3(kBlock), 0, st, xyz, n, L, mask, dxyz);
     return hipGetLastError();
 }
 
 hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
                                 const float* ty, const float* tz, size_t nt, const LrmCompiledLeg* legs_dev,
-                                int nlegs, uint8_t* out_leg_body, uint8_t* all_legs_out, hipStream_t st) {
+                                int nlegs, uint8_t* out_leg_body, uint8_t* all_legs_out, bool fast, hipStream_t st) {
     const dim3 grid((unsigned)((nb + kBodiesPerBlock - 1) / kBodiesPerBlock), (unsigned)nlegs);
-    hipLaunchKernelGGL(reach_any_kernel, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev,
-                       out_leg_body);
+    if (fast) hipLaunchKernelGGL(reach_any_kernel<true>, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev, out_leg_body);
+    else hipLaunchKernelGGL(reach_any_kernel<false>, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev, out_leg_body);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (all_legs_out) {

@@ -5,17 +5,18 @@
 
 hipError_t lrm_launch_warmup(size_t n, hipStream_t st);
 hipError_t lrm_launch_reach_soa(const float* x, const float* y, const float* z, size_t n,
-                                const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, hipStream_t st);
+                                const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, bool fast, hipStream_t st);
 // op: 1 = distance (mask = distance's validity byte, may be null), 2 = reach mask + distance
 hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const float* z, size_t n,
                                const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
-                               float* dz, hipStream_t st);
-hipError_t lrm_launch_reach_aos(const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask, hipStream_t st);
+                               float* dz, bool fast, hipStream_t st);
+hipError_t lrm_launch_reach_aos(const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask, bool fast,
+                                hipStream_t st);
 hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask,
-                               float* dxyz, hipStream_t st);
+                               float* dxyz, bool fast, hipStream_t st);
 hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
                                 const float* ty, const float* tz, size_t nt, const LrmCompiledLeg* legs_dev,
-                                int nlegs, uint8_t* out_leg_body, uint8_t* all_legs_out, hipStream_t st);
+                                int nlegs, uint8_t* out_leg_body, uint8_t* all_legs_out, bool fast, hipStream_t st);
 hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, const float* cz, size_t nc,
                                    const float* tx, const float* ty, const float* tz, size_t nt, float radius,
                                    float plus_z, float minus_z, uint8_t* out, hipStream_t st);

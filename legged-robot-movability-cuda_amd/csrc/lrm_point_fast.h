@@ -1,0 +1,365 @@
+// lrm_point_fast.h -- filtered evaluation (LRM_MODE_FAST) of the reach / distance path.
+//
+// Idea (floating-point filters, as in exact geometric predicates): every value that reaches
+// an OUTPUT is computed with the strict, reference-order arithmetic of lrm_point.h; every
+// DECISION on the way (which region, is the point inside a circle, is a clamp point valid,
+// which boundary is nearest, which coxa candidate wins) is first taken with cheap arithmetic
+// (FMA, squared distances instead of sqrt, cross products instead of atan2f, hardware
+// rsqrt/sqrt) together with a conservative bound on how far that arithmetic can be from the
+// strict one.  If a decision falls inside its band the point is flagged `uncertain` and the
+// caller re-evaluates it with the strict code.  Results are therefore bit-identical to the
+// strict mode by construction; the bands only decide how often the slow path runs (measured:
+// a few points per million).
+//
+// What the strict path spends and this one does not, per distance candidate:
+//   16 sqrt-bearing circle validations of clamp points  -> squared-domain tests
+//   4 + n_corners exact clamps (sqrt + div each)        -> 1 exact clamp (the winner's)
+//   1 exact atan2f for the region                       -> 2 cross products
+// and for reachability: both atan2f and the sincosf disappear (pure decisions).
+//
+// Error model (u = 2^-24).  All inputs of the decisions below (px, pz, the rotated
+// coordinates) are the strict values themselves, so only the decision arithmetic differs:
+//   m  = |p - c|^2 by FMA            : relative error <= 2u
+//   sqrt by v_sqrt_f32 / rsq         : <= 1 ulp  (strict: correctly rounded)
+//   strict d = r - sqrt(m) is exact by Sterbenz near the boundary; its sqrt carries 0.5 ulp
+//   => |d_fast - d_strict| <= 4u * mag  <= 2.4e-7 * S   with S = |px| + |pz| + fast_scale.
+// The band used is kBand * S with kBand = 4e-6 (>= 16x the bound).  Cross products:
+//   t = cosC*pz - sinC*px : error <= 4u (|px| + |pz|); the strict atan2f is within 1 ulp
+//   of the true angle, i.e. within 2e-7*|p| in t.  Band: kBand * (|px| + |pz|) (>= 8x).
+// In the reachability filter the plane abscissa itself is approximate (sgn(x)*sqrt(x^2+y^2)
+// instead of the strict x*cos(a) - y*sin(a), both within 4u*r of the true value): its error
+// <= 8u*r is added to S there.
+#pragma once
+#include "lrm_point.h"
+
+#define LRM_BAND 4.0e-6f
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LRM_FAST_SQRT(v) __builtin_amdgcn_sqrtf(v)
+#define LRM_FAST_RSQ(v) __builtin_amdgcn_rsqf(v)
+#else
+#define LRM_FAST_SQRT(v) sqrtf(v)
+#define LRM_FAST_RSQ(v) (1.0f / sqrtf(v))
+#endif
+
+// "atan2f(y, x) > C" for a constant C in (-pi, pi) given (cos C, sin C), as a half-plane
+// test with the wrap at +-pi handled; sets `unc` when the strict comparison could differ.
+LRM_HD bool lrm_dir_gt(float x, float y, float C, float cosC, float sinC, float band, uint32_t& unc) {
+#pragma clang fp contract(fast)
+    const float t = cosC * y - sinC * x; // > 0: (x,y) is counter-clockwise of direction C by < pi
+    unc |= !(fabsf(t) > band) ? 1u : 0u;
+    // the ray at +-pi: atan2f jumps from +pi (y = +0) to -pi (y = -0)
+    unc |= ((x < band) && !(fabsf(y) > band)) ? 2u : 0u;
+    const bool ypos = !(lrm_f2u(y) >> 31);
+    return (C >= 0.f) ? (t > 0.f && ypos) : (ypos || t > 0.f);
+}
+
+// find_region (circles.cu.h:48-78) without atan2f
+LRM_HD int lrm_region_fast(const LrmCompiledLeg& L, float x, float y, float band, uint32_t& unc) {
+    const bool upper = lrm_dir_gt(x, y, L.region_mid, L.dir_cos[0], L.dir_sin[0], band, unc);
+    const bool more = upper ? lrm_dir_gt(x, y, L.full_sat[1], L.dir_cos[2], L.dir_sin[2], band, unc)
+                            : lrm_dir_gt(x, y, L.full_sat[0], L.dir_cos[1], L.dir_sin[1], band, unc);
+    return (upper ? 2 : 0) + ((upper != more) ? 1 : 0);
+}
+
+// squared-domain validity of (x, y) against circle i of a list; band_d is the distance band
+LRM_HD bool lrm_valid_fast(const LrmCircle c, const LrmCompiledLeg::FastCircle f, float x, float y,
+                           float band_d, uint32_t& unc) {
+#pragma clang fp contract(fast)
+    const float dx = x - c.x, dy = y - c.y;
+    const float m = dx * dx + dy * dy;
+    const float q = m - f.T;
+    unc |= !(fabsf(q) > f.g * band_d) ? 4u : 0u;
+    return (q * f.sg) < 0.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// reachability_global: decisions only
+// ---------------------------------------------------------------------------------------
+LRM_HD bool lrm_reach_circles_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
+                                   const LrmCompiledLeg::FastCircle* flists, LrmVec3 p, uint32_t& unc) {
+    // place_over_coxa: strict arithmetic (cheap, and keeps the inputs of the filters exact)
+    p.x -= L.body;
+    const float buffer = p.x * L.sin_pitch;
+    p.x = p.x * L.cos_pitch - p.z * L.sin_pitch;
+    p.z = buffer + p.z * L.cos_pitch;
+    const bool flip = lrm_f2u(p.x) >> 31;
+    const float ax = flip ? -p.x : p.x;
+    const float ay = flip ? -p.y : p.y;
+    float r_xy, px;
+    {
+#pragma clang fp contract(fast)
+        r_xy = LRM_FAST_SQRT(ax * ax + ay * ay);
+        px = (flip ? -r_xy : r_xy) - L.coxa_length;
+    }
+    // yaw limits: angle = atan2f(ay, ax) with ax >= 0, limits inside (-pi/2, pi/2)
+    const float band_c = LRM_BAND * (ax + fabsf(ay));
+    const bool above = lrm_dir_gt(ax, ay, L.max_coxa, L.dir_cos[3], L.dir_sin[3], band_c, unc);
+    // angle < min  <=>  not (angle > min) and angle != min; equality sits inside the band
+    const bool not_below = lrm_dir_gt(ax, ay, L.min_coxa, L.dir_cos[4], L.dir_sin[4], band_c, unc);
+    if (above || !not_below) return false;
+    const float S = fabsf(px) + fabsf(p.z) + L.fast_scale + 2.0f * r_xy;
+    const float band = LRM_BAND * S;
+    const int reg = lrm_region_fast(L, px, p.z, band, unc);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < LRM_N_CIRCLES; i++)
+        ok = ok & lrm_valid_fast(lists[reg * LRM_N_CIRCLES + i], flists[reg * LRM_N_CIRCLES + i], px, p.z, band, unc);
+    return ok;
+}
+
+LRM_HD bool lrm_reach_global_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
+                                  const LrmCompiledLeg::FastCircle* flists, LrmVec3 p, uint32_t& unc) {
+    LrmVec3 u = lrm_qrot(L.inv_rot, p);
+    const float buffer = u.x * L.sin_body;
+    u.x = u.x * L.cos_body - u.y * L.sin_body;
+    u.y = buffer + u.y * L.cos_body;
+    // non-finite coordinates: every band test above fails closed (NaN compares false)
+    return lrm_reach_circles_fast(L, lists, flists, u, unc);
+}
+
+LRM_HD bool lrm_reachable_rotate_leg_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
+                                          const LrmCompiledLeg::FastCircle* flists, LrmVec3 t, LrmVec3 body,
+                                          uint32_t& unc) {
+    t.x -= body.x;
+    t.y -= body.y;
+    t.z -= body.z;
+    const LrmVec3 g = lrm_qrot(L.inv_rot, t);
+    const float gx = g.x * L.cos_body - g.y * L.sin_body;
+    if (gx < 0) return false;
+    const float buffer = t.x * L.sin_body;
+    t.x = t.x * L.cos_body - t.y * L.sin_body;
+    t.y = buffer + t.y * L.cos_body;
+    return lrm_reach_circles_fast(L, lists, flists, t, unc);
+}
+
+// ---------------------------------------------------------------------------------------
+// distance_global: filtered decisions + strict arithmetic for the winner
+// ---------------------------------------------------------------------------------------
+
+// eval_plane_circles<DIST> + multi_circle_clamp with filtered decisions.  (x, y) in/out as in
+// lrm_plane_dist.  A decision inside its band sends this ONE call to the strict
+// lrm_plane_dist (same inputs, same outputs); a near-tie between the two nearest boundaries is
+// resolved by evaluating just those two with the strict clamp.  `unc` is only a statistic here.
+LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
+                                const LrmCompiledLeg::FastCircle* flists, float& x, float& y, uint32_t& unc) {
+    const float x_in = x, y_in = y;
+    x -= L.coxa_length;
+    uint32_t lu = 0;
+    const float S = fabsf(x) + fabsf(y) + L.fast_scale;
+    const float band = LRM_BAND * S;
+    const float band_q = LRM_BAND * (2.0f * L.fast_scale); // clamp points live on the circles
+    const int reg = lrm_region_fast(L, x, y, band, lu);
+    const LrmCircle* list = lists + reg * LRM_N_CIRCLES;
+    const LrmCompiledLeg::FastCircle* flist = flists + reg * LRM_N_CIRCLES;
+
+    bool overall = true;
+    float best = 3.0e38f, second = 3.0e38f, third = 3.0e38f; // approximate |d|, ascending
+    int win = -1, win2 = -1;                                 // 0..3 circle, 4.. corner, -1 none
+#pragma unroll
+    for (int i = 0; i < LRM_N_CIRCLES; i++) {
+        const LrmCircle c = list[i];
+        const LrmCompiledLeg::FastCircle f = flist[i];
+        float vx, vy, m, ad, qx, qy;
+        {
+#pragma clang fp contract(fast)
+            vx = x - c.x;
+            vy = y - c.y;
+            m = vx * vx + vy * vy;
+            const float q = m - f.T;
+            lu |= !(fabsf(q) > f.g * band) ? 8u : 0u;
+            overall = overall & ((q * f.sg) < 0.f);
+            const float rs = LRM_FAST_RSQ(m);
+            const float mag = m * rs;
+            ad = fabsf(c.r - mag);
+            // the strict clamp replaces the direction by (1,0) when mag < margin (one_leg.cu:54-58)
+            lu |= !(mag > 0.01f) ? 16u : 0u;
+            const float k = c.r * rs;
+            qx = c.x + vx * k;
+            qy = c.y + vy * k;
+        }
+        // validity of the clamp point against the other three circles (its own: |d| ~ 0 < margin)
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < LRM_N_CIRCLES; j++)
+            if (j != i) ok = ok & lrm_valid_fast(list[j], flist[j], qx, qy, band_q, lu);
+        if (ok) {
+            if (ad < best) { third = second; second = best; win2 = win; best = ad; win = i; }
+            else if (ad < second) { third = second; second = ad; win2 = i; }
+            else if (ad < third) { third = ad; }
+        }
+    }
+    if (!overall) {
+        for (int i = 0; i < L.n_ucorners; i++) {
+            float ad;
+            {
+#pragma clang fp contract(fast)
+                const float vx = x - L.ucorner_x[i], vy = y - L.ucorner_y[i];
+                ad = LRM_FAST_SQRT(vx * vx + vy * vy);
+            }
+            const int id = LRM_N_CIRCLES + i;
+            if (ad < best) { third = second; second = best; win2 = win; best = ad; win = id; }
+            else if (ad < second) { third = second; second = ad; win2 = id; }
+            else if (ad < third) { third = ad; }
+        }
+    }
+    const float tie = 2.0f * band;
+    lu |= (win < 0) ? 32u : 0u;                      // nothing to clamp on: let the strict code say so
+    lu |= !(third - best > tie) ? 32u : 0u;          // three-way near-tie
+    unc |= lu;
+    if (lu) { // strict evaluation of this call (rare: a few 1e-4 of the calls)
+        x = x_in;
+        y = y_in;
+        return lrm_plane_dist(L, lists, x, y);
+    }
+    // strict arithmetic for the winner (and the runner-up when the filter cannot separate them)
+    float bx, by, d1;
+    {
+        float cx, cy, cr;
+        bool attract = true, v;
+        if (win < LRM_N_CIRCLES) { const LrmCircle c = list[win]; cx = c.x; cy = c.y; cr = c.r; attract = c.attract != 0.f; }
+        else { cx = L.ucorner_x[win - LRM_N_CIRCLES]; cy = L.ucorner_y[win - LRM_N_CIRCLES]; cr = 0.f; }
+        bx = x;
+        by = y;
+        lrm_clamp_on(cx, cy, cr, attract, bx, by, d1, v);
+    }
+    if (!(second - best > tie)) {
+        unc |= 256u; // statistic: local exact tie-break
+        float cx, cy, cr, b2x = x, b2y = y, d2;
+        bool attract = true, v;
+        if (win2 < LRM_N_CIRCLES) { const LrmCircle c = list[win2]; cx = c.x; cy = c.y; cr = c.r; attract = c.attract != 0.f; }
+        else { cx = L.ucorner_x[win2 - LRM_N_CIRCLES]; cy = L.ucorner_y[win2 - LRM_N_CIRCLES]; cr = 0.f; }
+        lrm_clamp_on(cx, cy, cr, attract, b2x, b2y, d2, v);
+        // the strict loop keeps the earlier entry unless the later one is strictly closer
+        const bool first_is_win = win < win2;
+        const float df = first_is_win ? d1 : d2, dl = first_is_win ? d2 : d1;
+        const bool later_wins = fabsf(df) > fabsf(dl);
+        const bool take2 = (first_is_win == later_wins);
+        bx = take2 ? b2x : bx;
+        by = take2 ? b2y : by;
+    }
+    x -= bx;
+    y -= by;
+    return overall;
+}
+
+// finish_finding_closest<bool> (one_leg.cu:215-278); `angle` is the strict atan2f value, so
+// every comparison on it is the strict comparison.
+LRM_HD bool lrm_finish_closest_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
+                                    const LrmCompiledLeg::FastCircle* flists, LrmVec3& p, float angle,
+                                    uint32_t& unc) {
+    const bool mega = (angle > L.mega_hi) || (angle < L.mega_lo);
+    float sat;
+    if (mega) sat = (angle > 0) ? angle - LRM_PI_F : angle + LRM_PI_F;
+    else sat = fmaxf(fminf(angle, L.max_coxa), L.min_coxa);
+    const bool saturated = sat != angle;
+    const float limit = (angle > L.coxa_mid) ? L.max_coxa : L.min_coxa;
+    float s, c;
+    lrm_sincosf(-sat, &s, &c);
+    float buffer = p.x * s;
+    p.x = p.x * c - p.y * s;
+    p.y = buffer + p.y * c;
+    const LrmVec3 save = p;
+    const bool was_valid = lrm_plane_dist_fast(L, lists, flists, p.x, p.z, unc);
+    if (was_valid && !mega) {
+        // Is the nearer yaw-limit half-plane closer than the in-plane boundary?  Filter first:
+        // |save.x*sin(th) + save.y*cos(th)| against |p|, th = -(limit - sat).
+        const float th = -(limit - sat);
+        const float Sxy = fabsf(save.x) + fabsf(save.y);
+        float nrm, d_lim;
+        {
+#pragma clang fp contract(fast)
+            nrm = LRM_FAST_SQRT(p.x * p.x + p.y * p.y + p.z * p.z);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const float s2 = __sinf(th), c2 = __cosf(th); // hardware sin/cos: abs error < 2e-6
+#else
+            const float s2 = sinf(th), c2 = cosf(th);
+#endif
+            d_lim = fabsf(save.x * s2 + save.y * c2);
+        }
+        const float band2 = LRM_BAND * (Sxy + fabsf(p.z) + L.fast_scale) + 8.0e-6f * Sxy;
+        const bool near = !(fabsf(nrm - d_lim) > band2);
+        if (near || nrm > d_lim) {
+            // strict arithmetic (one_leg.cu:258-272): decides when `near`, and produces the output
+            unc |= near ? 64u : 0u;
+            float s2, c2;
+            lrm_sincosf(th, &s2, &c2);
+            const float sy = save.x * s2 + save.y * c2;
+            LrmVec3 lim = {0.f, sy, 0.f};
+            if (lrm_norm3(p) > lrm_norm3(lim)) {
+                const float b2 = lim.y * s2;
+                lim.y = -lim.x * s2 + lim.y * c2;
+                lim.x = lim.x * c2 + b2;
+                p = lim;
+            }
+        }
+    }
+    buffer = p.y * s;
+    p.y = -p.x * s + p.y * c;
+    p.x = p.x * c + buffer;
+    return was_valid && !saturated;
+}
+
+LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
+                                  const LrmCompiledLeg::FastCircle* flists, LrmVec3& r, uint32_t& unc) {
+    LrmVec3 a = r;
+    a.x -= L.body;
+    float buffer = a.x * L.sin_pitch;
+    a.x = a.x * L.cos_pitch - a.z * L.sin_pitch;
+    a.z = buffer + a.z * L.cos_pitch;
+    LrmVec3 b = a;
+    const float ang = lrm_atan2f(a.y, a.x);
+    const float ang_flip = (ang > 0) ? ang - LRM_PI_F : ang + LRM_PI_F;
+    const bool res = lrm_finish_closest_fast(L, lists, flists, a, ang, unc);
+    const bool resflip = lrm_finish_closest_fast(L, lists, flists, b, ang_flip, unc);
+    // The two candidates are often the same configuration up to rounding (yaw within 30 deg of
+    // the axis: one of them is "mega-saturated" onto the other): the strict comparison of the
+    // strict norms is the only way to pick the same one.
+    const bool use_direct = (res == resflip) ? (lrm_norm3(a) < lrm_norm3(b)) : res;
+    r = use_direct ? a : b;
+    buffer = r.x * L.sin_pitch_rev;
+    r.x = r.x * L.cos_pitch_rev - r.z * L.sin_pitch_rev;
+    r.z = buffer + r.z * L.cos_pitch_rev;
+    return res || resflip;
+}
+
+LRM_HD bool lrm_dist_global_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
+                                 const LrmCompiledLeg::FastCircle* flists, LrmVec3& p, uint32_t& unc) {
+    LrmVec3 u = lrm_qrot(L.inv_rot, p);
+    float buffer = u.x * L.sin_body;
+    u.x = u.x * L.cos_body - u.y * L.sin_body;
+    u.y = buffer + u.y * L.cos_body;
+    const bool r = lrm_dist_circles_fast(L, lists, flists, u, unc);
+    buffer = u.x * -L.sin_body;
+    u.x = u.x * L.cos_body - u.y * -L.sin_body;
+    u.y = buffer + u.y * L.cos_body;
+    p = lrm_qrot(L.fwd_rot, u);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// Self-contained filtered entry points: the strict re-evaluation is inside, so callers get
+// the strict result bit for bit whatever the bands decide.
+// ---------------------------------------------------------------------------------------
+LRM_HD bool lrm_reach_global_filtered(const LrmCompiledLeg& L, const LrmCircle* lists,
+                                      const LrmCompiledLeg::FastCircle* flists, LrmVec3 p) {
+    uint32_t unc = 0;
+    bool r = lrm_reach_global_fast(L, lists, flists, p, unc);
+    if (unc) r = lrm_reach_global(L, lists, p);
+    return r;
+}
+
+LRM_HD bool lrm_reachable_rotate_leg_filtered(const LrmCompiledLeg& L, const LrmCircle* lists,
+                                              const LrmCompiledLeg::FastCircle* flists, LrmVec3 t,
+                                              LrmVec3 body) {
+    uint32_t unc = 0;
+    bool r = lrm_reachable_rotate_leg_fast(L, lists, flists, t, body, unc);
+    if (unc) r = lrm_reachable_rotate_leg(L, lists, t, body);
+    return r;
+}
+
+LRM_HD bool lrm_dist_global_filtered(const LrmCompiledLeg& L, const LrmCircle* lists,
+                                     const LrmCompiledLeg::FastCircle* flists, LrmVec3& p) {
+    uint32_t stat = 0; // the distance filter resolves its own doubts (see lrm_plane_dist_fast)
+    return lrm_dist_global_fast(L, lists, flists, p, stat);
+}

@@ -45,7 +45,21 @@ struct LrmCompiledLeg {
     float coxa_mid;                     // (max_coxa + min_coxa)/2           one_leg.cu:229
     float region_mid;                   // circles.cu.h:52-54
     float full_sat[2];                  // circles.cu.h:68, indexed by UpperRegion
-    // ---- derived constants of the filtered (LRM_MODE_FAST) evaluation ----
     float reach_r2_max;                 // (body-frame) squared radius beyond which nothing is reachable
-    float pad[2];
+    // ---- constants of the filtered (LRM_MODE_FAST) evaluation: lrm_point_fast.h ----
+    // squared-domain validity test of circle lists[k][i]:  valid <=> sg*(m - T) < 0 with
+    // m = |p - c|^2;  T = (r + margin)^2, sg = +1 (attractive) or T = (r - margin)^2, sg = -1;
+    // g = 2*(r + margin) converts a distance band into a band on m.
+    struct FastCircle {
+        float T, sg, g, pad;
+    } flists[4][LRM_N_CIRCLES];
+    // direction tests "angle > C" as cross products: (cos C, sin C) for
+    // C = region_mid, full_sat[0], full_sat[1], max_coxa, min_coxa
+    float dir_cos[5], dir_sin[5];
+    float fast_scale;                   // max over circles of |cx| + |cy| + r (mm)
+    int32_t fast_ok;                    // 0: this leg must take the strict path everywhere
+    int32_t n_ucorners;                 // corner points with exact duplicates removed
+    float ucorner_x[LRM_N_CORNERS];
+    float ucorner_y[LRM_N_CORNERS];
+    float pad_[1];
 };

@@ -117,3 +117,43 @@ def test_exact_math_host_matches_glibc(lrm):
         libm.sincosf(float(a[i]), C.byref(s_), C.byref(c_))
         ws[k], wc[k] = s_.value, c_.value
     assert bits_equal(sn[sel], ws).all() and bits_equal(cs[sel], wc).all()
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_filtered_evaluation_on_host_matches_fixture(lrm, name):
+    """csrc/lrm_point_fast.h (LRM_MODE_FAST) compiled for the host, without the caller-side
+    fallback: the distance field and its validity byte are bit-identical on EVERY point (the
+    filter resolves its doubts internally); the reach mask is identical wherever the filter does
+    not raise its `uncertain` flag (flagged points are re-evaluated by the strict code)."""
+    c = load_case(name)
+    f = lrm.dbg_fast_host(c["points"], c["leg"], c["quat"])
+    sure = f["mask_unc"] == 0
+    assert np.array_equal(f["mask"][sure], c["mask"][sure])
+    assert np.array_equal(f["valid"], c["valid"])
+    assert bits_equal(f["dist"], c["dist"]).all()
+    if name.startswith("cube"):
+        assert 1 - sure.mean() < 1e-3  # the strict fallback is rare on ordinary clouds
+
+
+def test_filtered_evaluation_random_legs_and_clouds(lrm):
+    """Random legs (within the filter's eligibility) x orientations x clouds: filtered == strict."""
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for trial in range(12):
+        leg = lrm.leg_factory(rng.uniform(-3, 3), rng.uniform(80, 250), rng.uniform(-60, 30), rng.uniform(30, 90),
+                              rng.uniform(90, 160), rng.uniform(90, 170), rng.uniform(30, 80), rng.uniform(60, 100),
+                              rng.uniform(90, 140), rng.uniform(-20, 10), rng.uniform(-20, 10))
+        q = rng.normal(size=4).astype(np.float32)
+        q[0] += 3.0
+        pts = random_cloud(60000, seed=trial)
+        try:
+            f = lrm.dbg_fast_host(pts, leg, q)
+        except lrm.LrmError:
+            continue  # leg outside the filter's eligibility: the library uses the strict path
+        m, _ = lrm.apply_reach_cpu(pts, leg, q)
+        d, v, _ = lrm.apply_dist_cpu(pts, leg, q)
+        sure = f["mask_unc"] == 0
+        assert np.array_equal(f["mask"][sure], m[sure])
+        assert np.array_equal(f["valid"], v) and bits_equal(f["dist"], d).all()
+        checked += 1
+    assert checked >= 8

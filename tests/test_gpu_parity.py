@@ -12,6 +12,14 @@ from conftest import bits_equal, golden_cases, load_case, random_cloud
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["strict", "fast"])
+def mode(request, lrm):
+    """Every GPU test runs in both arithmetic modes; both must be bit-identical to the oracle."""
+    lrm.set_mode(lrm.MODE_FAST if request.param == "fast" else lrm.MODE_STRICT)
+    yield request.param
+    lrm.set_mode(lrm.MODE_STRICT)
+
+
 @pytest.fixture(scope="module")
 def torch_cuda():
     import torch
