@@ -30,9 +30,11 @@ extern "C" {
  * LRM_MODE_STRICT: reference operation order, no FMA contraction, glibc-exact atan2f/sincosf:
  *                  bit-identical to the reference's host path (reachability_kernel_cpu /
  *                  distance_kernel_cpu, one_leg_global.cu:132-147).
- * LRM_MODE_FAST:   filtered evaluation: hoisted/algebraically simplified predicates with
- *                  conservative error bands; any point whose decision falls inside a band is
- *                  re-evaluated by the strict code, so the mask stays bit-identical. */
+ * LRM_MODE_FAST:   filtered evaluation (csrc/lrm_point_fast.h): decisions are taken with cheap
+ *                  arithmetic plus conservative error bands, values that reach an output are
+ *                  computed with the strict arithmetic, and any decision inside its band is
+ *                  re-taken by the strict code: outputs are bit-identical to LRM_MODE_STRICT.
+ *                  Legs outside the filter's eligibility silently use the strict kernels. */
 #define LRM_MODE_STRICT 0
 #define LRM_MODE_FAST 1
 
@@ -59,7 +61,7 @@ const char* lrm_version(void);
 const char* lrm_last_error(void);
 int lrm_device_count(void);          /* number of HIP devices, 0 if none (never fails)      */
 int lrm_set_device(int ordinal);     /* cudaSetDevice analogue; the reference uses device 0 */
-int lrm_set_mode(int mode);          /* LRM_MODE_*; process-wide default for all launches   */
+int lrm_set_mode(int mode);          /* LRM_MODE_*; process-wide; default LRM_MODE_FAST     */
 int lrm_get_mode(void);
 
 /* ---- leg factories: static_variables.cpp:6-93 ---------------------------------------- */

@@ -10,3 +10,4 @@ from ._capi import (  # noqa: F401
     exported_symbols, declared_symbols, dbg_fast_host,
 )
 from . import device  # noqa: F401
+from . import shard  # noqa: F401

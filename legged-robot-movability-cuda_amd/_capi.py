@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblrm.so")
+# LRM_LIB_PATH: load another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("LRM_LIB_PATH") or os.path.join(_HERE, "liblrm.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lrm.h")
 MODE_STRICT, MODE_FAST = 0, 1
 _lib = None

@@ -14,7 +14,7 @@
 namespace {
 
 thread_local std::string g_err;
-int g_mode = LRM_MODE_STRICT;
+int g_mode = LRM_MODE_FAST; // bit-identical to LRM_MODE_STRICT (tests/test_gpu_parity.py runs both)
 const float kQuatTest[4] = {1.f, 0.f, 0.f, 0.f}; // settings.h:51
 
 int fail(int code, const char* what) {

@@ -16,7 +16,7 @@
 //    its FMA variant on AVX2 hosts; with fused multiply-adds this restatement matches that
 //    variant on all 2.2e9 floats with |x| < 120, and with or without FMA on |x| < 7 (the
 //    only range the path produces: angles in [-2pi, 2pi]).  tests/test_exact_math.py checks it.
-//    |x| >= 120, inf and nan take the platform sincosf (never reached by the path).
+//    |x| >= 120 (never produced by the path) is answered with nan, like inf and nan.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -151,10 +151,10 @@ LRM_HD void lrm_sincosf(float y, float* sinp, float* cosp) {
         if (n & 2) csign = -1.0;
         x = x * s;
     } else {
-        float s_, c_;
-        sincosf(y, &s_, &c_);
-        *sinp = s_;
-        *cosp = c_;
+        // |y| >= 120, inf, nan: outside the emulated range (the path only produces angles in
+        // [-2pi, 2pi]).  inf/nan give nan as in glibc; a finite argument this large gives nan as
+        // well, so that a misuse is loud instead of silently inexact.
+        *sinp = *cosp = y - y + __builtin_nanf("");
         return;
     }
     const double x2 = x * x;

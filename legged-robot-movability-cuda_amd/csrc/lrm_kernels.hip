@@ -19,6 +19,12 @@
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef LRM_DIST_MIN_WAVES
+#define LRM_DIST_MIN_WAVES 1
+#endif
+#ifndef LRM_REACH_MIN_WAVES
+#define LRM_REACH_MIN_WAVES 1
+#endif
 
 // LDS image of the per-lane-indexed tables: 16 circles + their 16 filter records (512 B)
 struct LdsTables {
@@ -59,7 +65,7 @@ __device__ __forceinline__ bool eval_pair(const LrmCompiledLeg& L, const LdsTabl
 // three 16-byte loads in, one 4-byte store out.
 // ------------------------------------------------------------------------------------
 template <bool kBits, bool kFast>
-__global__ __launch_bounds__(kBlock) void reach_soa_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(kBlock, LRM_REACH_MIN_WAVES) void reach_soa_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ y,
                                                            const float* __restrict__ z, size_t n,
                                                            const LrmCompiledLeg L,
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void reach_soa_scalar_kernel(const float* _
 // kOp: 1 = distance (+ optional validity byte), 2 = reach mask + distance.
 // ------------------------------------------------------------------------------------
 template <int kOp, bool kFast>
-__global__ __launch_bounds__(kBlock) void dist_soa_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(kBlock, LRM_DIST_MIN_WAVES) void dist_soa_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ y,
                                                           const float* __restrict__ z, size_t n,
                                                           const LrmCompiledLeg L,

@@ -64,6 +64,7 @@ def test_empty_and_null_arguments(lrm):
     assert rc == -1
     assert L.lrm_set_mode(7) == -1
     assert L.lrm_set_mode(0) == 0 and L.lrm_get_mode() == 0
+    assert L.lrm_set_mode(1) == 0 and L.lrm_get_mode() == 1  # back to the default
 
 
 def test_gpu_entry_points_fail_loudly_without_a_device(lrm):

@@ -17,7 +17,7 @@ def mode(request, lrm):
     """Every GPU test runs in both arithmetic modes; both must be bit-identical to the oracle."""
     lrm.set_mode(lrm.MODE_FAST if request.param == "fast" else lrm.MODE_STRICT)
     yield request.param
-    lrm.set_mode(lrm.MODE_STRICT)
+    lrm.set_mode(lrm.MODE_FAST)  # the library default
 
 
 @pytest.fixture(scope="module")
