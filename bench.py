@@ -30,6 +30,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 BYTES_PER_EVAL = {"reach": 13, "dist": 24, "reach_dist": 25}
 
 
+def measured_traffic(points, mode, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md prescribes); None when no
+    committed measurement matches this workload.  PMC counters cannot be read from inside the
+    timed run, so this is the figure of the latest profiled run of the same command."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("points_per_launch") == points and rec.get("mode") == mode and kernel in rec.get("kernels", {}):
+            return rec["kernels"][kernel]["hbm_bytes_per_launch"], os.path.basename(path)
+    return None, None
+
+
 def make_cloud(n, seed):
     rng = np.random.default_rng(seed)
     lo = np.array([-200, -500, -500], np.float32)
@@ -187,6 +203,8 @@ def main():
     if rank == 0:
         total_evals = float(n) * world * args.steps
         achieved = BYTES_PER_EVAL["reach_dist"] * n / (kernel_ms * 1e-3) / 1e9
+        kname = "dist_soa_kernel<2, true>" if mode == "fast" else "dist_soa_kernel<2, false>"
+        traffic, traffic_src = measured_traffic(n, mode, kname)
         line = {
             "metric": "leg-target evaluations/sec (reach+dist)",
             "value": total_evals / elapsed,
@@ -209,9 +227,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "dist_soa_kernel<2> (fused reach+distance)", "kernel_ms": kernel_ms,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": kname + " (fused reach+distance)", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_eval": BYTES_PER_EVAL["reach_dist"],
+                "algorithmic_bytes_per_launch": BYTES_PER_EVAL["reach_dist"] * n,
             },
             "kernels": extra,
         }
