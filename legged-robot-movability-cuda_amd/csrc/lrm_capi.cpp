@@ -326,7 +326,7 @@ int lrm_dbg_fast_host(const float* xyz, size_t n, const LrmLegDimensions* leg, c
         const LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         if (mask_out) {
             uint32_t unc = 0;
-            mask_out[i] = lrm_reach_global_fast(L, &L.lists[0][0], &L.flists[0][0], p, unc);
+            mask_out[i] = lrm_reach_global_fast(L, &L.lean[0][0], p, unc);
             if (mask_unc_out) mask_unc_out[i] = (uint8_t)unc;
         }
         if (dxyz_out) {

@@ -259,6 +259,47 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
         }
     }
 
+    // lean reach filter: affine maps (double on the host, from the same float coefficients the
+    // strict code multiplies with) and 16-byte circle records
+    {
+        double Rq[3][3], Rz[3][3] = {{out->cos_body, -(double)out->sin_body, 0}, {out->sin_body, out->cos_body, 0}, {0, 0, 1}};
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) Rq[r][k] = 2.0 * out->inv_rot[3 * r + k] + (r == k ? 1.0 : 0.0);
+        const double Rp[3][3] = {{out->cos_pitch, 0, -(double)out->sin_pitch}, {0, 1, 0}, {out->sin_pitch, 0, out->cos_pitch}};
+        double RzRq[3][3], G[3][3], P[3][3];
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) {
+                RzRq[r][k] = 0;
+                for (int j = 0; j < 3; j++) RzRq[r][k] += Rz[r][j] * Rq[j][k];
+            }
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) {
+                G[r][k] = P[r][k] = 0;
+                for (int j = 0; j < 3; j++) {
+                    G[r][k] += Rp[r][j] * RzRq[j][k];
+                    P[r][k] += Rp[r][j] * Rz[j][k];
+                }
+            }
+        for (int r = 0; r < 3; r++) {
+            for (int k = 0; k < 3; k++) {
+                out->aff_global[4 * r + k] = (float)G[r][k];
+                out->aff_pair[4 * r + k] = (float)P[r][k];
+            }
+            const float tr = (float)(-Rp[r][0] * (double)l.body);
+            out->aff_global[4 * r + 3] = tr;
+            out->aff_pair[4 * r + 3] = tr;
+        }
+        for (int k = 0; k < 3; k++) out->grav_row[k] = (float)RzRq[0][k];
+        for (int k = 0; k < 4; k++)
+            for (int i = 0; i < LRM_N_CIRCLES; i++) {
+                auto& q = out->lean[k][i];
+                q.x = out->lists[k][i].x;
+                q.y = out->lists[k][i].y;
+                q.T = out->flists[k][i].T;
+                q.gs = (float)((double)out->flists[k][i].sg / (double)out->flists[k][i].g);
+            }
+    }
+
     // Nothing farther than the stretched leg (+1 mm and 1e-4 relative slack, three orders of
     // magnitude above the float rounding of the strict evaluation) can pass the attractive
     // circle test, so pairs beyond this radius are skipped without changing any result.

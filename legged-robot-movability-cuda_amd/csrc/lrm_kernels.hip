@@ -26,19 +26,22 @@ constexpr int kBlock = 256;
 #define LRM_REACH_MIN_WAVES 1
 #endif
 
-// LDS image of the per-lane-indexed tables: 16 circles + their 16 filter records (512 B)
+// LDS image of the per-lane-indexed tables: 16 circles + their filter records (768 B)
 struct LdsTables {
     LrmCircle lists[16];
     LrmCompiledLeg::FastCircle flists[16];
+    LrmCompiledLeg::LeanCircle lean[16];
 };
 
 __device__ __forceinline__ void stage_lists(const LrmCompiledLeg& L, LdsTables* t) {
     // 2 x 64 floats; one float of each table per thread of the first wave
     const float* src = reinterpret_cast<const float*>(&L.lists[0][0]);
     const float* fsrc = reinterpret_cast<const float*>(&L.flists[0][0]);
+    const float* lsrc = reinterpret_cast<const float*>(&L.lean[0][0]);
     if (threadIdx.x < 64) {
         reinterpret_cast<float*>(t->lists)[threadIdx.x] = src[threadIdx.x];
         reinterpret_cast<float*>(t->flists)[threadIdx.x] = fsrc[threadIdx.x];
+        reinterpret_cast<float*>(t->lean)[threadIdx.x] = lsrc[threadIdx.x];
     }
     __syncthreads();
 }
@@ -46,7 +49,7 @@ __device__ __forceinline__ void stage_lists(const LrmCompiledLeg& L, LdsTables* 
 // mode dispatch: kFast selects the filtered evaluation (bit-identical, see lrm_point_fast.h)
 template <bool kFast>
 __device__ __forceinline__ bool eval_reach(const LrmCompiledLeg& L, const LdsTables* t, LrmVec3 p) {
-    if (kFast) return lrm_reach_global_filtered(L, t->lists, t->flists, p);
+    if (kFast) return lrm_reach_global_filtered(L, t->lists, t->lean, p);
     return lrm_reach_global(L, t->lists, p);
 }
 template <bool kFast>
@@ -56,7 +59,7 @@ __device__ __forceinline__ bool eval_dist(const LrmCompiledLeg& L, const LdsTabl
 }
 template <bool kFast>
 __device__ __forceinline__ bool eval_pair(const LrmCompiledLeg& L, const LdsTables* t, LrmVec3 tg, LrmVec3 body) {
-    if (kFast) return lrm_reachable_rotate_leg_filtered(L, t->lists, t->flists, tg, body);
+    if (kFast) return lrm_reachable_rotate_leg_filtered(L, t->lists, t->lean, tg, body);
     return lrm_reachable_rotate_leg(L, t->lists, tg, body);
 }
 

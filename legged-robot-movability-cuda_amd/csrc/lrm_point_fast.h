@@ -32,7 +32,9 @@
 #pragma once
 #include "lrm_point.h"
 
+#ifndef LRM_BAND
 #define LRM_BAND 4.0e-6f
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LRM_FAST_SQRT(v) __builtin_amdgcn_sqrtf(v)
@@ -74,63 +76,100 @@ LRM_HD bool lrm_valid_fast(const LrmCircle c, const LrmCompiledLeg::FastCircle f
 }
 
 // ---------------------------------------------------------------------------------------
-// reachability_global: decisions only
+// reachability: decisions only.  Lean form: one affine map into the coxa frame, every test
+// turned into a signed distance-to-the-decision-boundary in mm ("value"); the decision is the
+// sign of the largest value, the doubt is the smallest |value| against one band.  No
+// compare/select chains: v_max / v_min accumulators.
 // ---------------------------------------------------------------------------------------
-LRM_HD bool lrm_reach_circles_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
-                                   const LrmCompiledLeg::FastCircle* flists, LrmVec3 p, uint32_t& unc) {
-    // place_over_coxa: strict arithmetic (cheap, and keeps the inputs of the filters exact)
-    p.x -= L.body;
-    const float buffer = p.x * L.sin_pitch;
-    p.x = p.x * L.cos_pitch - p.z * L.sin_pitch;
-    p.z = buffer + p.z * L.cos_pitch;
-    const bool flip = lrm_f2u(p.x) >> 31;
-    const float ax = flip ? -p.x : p.x;
-    const float ay = flip ? -p.y : p.y;
-    float r_xy, px;
+
+// "atan2f(y, x) > C" from the cross product t = cosC*y - sinC*x (see lrm_dir_gt)
+LRM_HD bool lrm_gt_from_t(float t, bool ypos, bool c_nonneg) {
+    const bool tp = t > 0.f;
+    return c_nonneg ? (tp && ypos) : (ypos || tp);
+}
+
+// (x, y, z): the point in the coxa frame (after place_over_coxa), possibly approximate with an
+// absolute error covered by `extra` (mm, before the LRM_BAND factor).
+LRM_HD bool lrm_reach_coxa_lean(const LrmCompiledLeg& L, const LrmCompiledLeg::LeanCircle* lean, float x, float y,
+                                float z, float extra, uint32_t& unc) {
+#pragma clang fp contract(fast)
+    const uint32_t sx = lrm_f2u(x) & 0x80000000u;
+    const float ax = fabsf(x);
+    const float ay = lrm_u2f(lrm_f2u(y) ^ sx); // the reference mirrors the point into x >= 0 (one_leg.cu:291-296)
+    const float r_xy = LRM_FAST_SQRT(ax * ax + ay * ay);
+    const float px = lrm_u2f(lrm_f2u(r_xy) | sx) - L.coxa_length;
+    const float S = L.fast_scale + (ax + fabsf(ay) + fabsf(z)) + extra; // r_xy: 8u*r << LRM_BAND*r
+    const float band = LRM_BAND * S;
+    // yaw limits (both inside (-pi/2, pi/2), ax >= 0): above <=> t_max > 0, below <=> t_min < 0
+    const float t_max = L.dir_cos[3] * ay - L.dir_sin[3] * ax;
+    const float t_min = L.dir_cos[4] * ay - L.dir_sin[4] * ax;
+    const float coxa_v = fmaxf(t_max, -t_min);
+    const float coxa_m = fminf(fabsf(t_max), fabsf(t_min));
+    // region (circles.cu.h:48-78)
+    const float t_mid = L.dir_cos[0] * z - L.dir_sin[0] * px;
+    const float t_s0 = L.dir_cos[1] * z - L.dir_sin[1] * px;
+    const float t_s1 = L.dir_cos[2] * z - L.dir_sin[2] * px;
+    const bool ypos = !(lrm_f2u(z) >> 31);
+    const bool upper = lrm_gt_from_t(t_mid, ypos, L.region_mid >= 0.f);
+    const bool more0 = lrm_gt_from_t(t_s0, ypos, L.full_sat[0] >= 0.f);
+    const bool more1 = lrm_gt_from_t(t_s1, ypos, L.full_sat[1] >= 0.f);
+    const bool more = upper ? more1 : more0;
+    const int reg = (upper ? 2 : 0) + ((upper != more) ? 1 : 0);
+    // doubt of the region: distance to any of the three rays, or to the atan2f wrap ray (x < 0, y = +-0)
+    float macc = fminf(fminf(fabsf(t_mid), fabsf(t_s0)), fminf(fabsf(t_s1), fmaxf(px, fabsf(z))));
+    const LrmCompiledLeg::LeanCircle* c = lean + reg * LRM_N_CIRCLES;
+    float vacc = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < LRM_N_CIRCLES; i++) {
+        const LrmCompiledLeg::LeanCircle ci = c[i];
+        const float dx = px - ci.x, dy = z - ci.y;
+        const float v = (dx * dx + dy * dy - ci.T) * ci.gs;
+        vacc = fmaxf(vacc, v);
+        macc = fminf(macc, fabsf(v));
+    }
+    const bool coxa_ok = coxa_v < 0.f;
+    // outside the yaw range the answer is "no" whatever the circles say
+    unc |= (!(coxa_m > band) || (coxa_ok && !(macc > band))) ? 1u : 0u;
+    return coxa_ok && (vacc < 0.f);
+}
+
+LRM_HD bool lrm_reach_global_fast(const LrmCompiledLeg& L, const LrmCompiledLeg::LeanCircle* lean, LrmVec3 p,
+                                  uint32_t& unc) {
+    float x, y, z, mag;
     {
 #pragma clang fp contract(fast)
-        r_xy = LRM_FAST_SQRT(ax * ax + ay * ay);
-        px = (flip ? -r_xy : r_xy) - L.coxa_length;
+        const float* a = L.aff_global;
+        x = a[0] * p.x + a[1] * p.y + a[2] * p.z + a[3];
+        y = a[4] * p.x + a[5] * p.y + a[6] * p.z + a[7];
+        z = a[8] * p.x + a[9] * p.y + a[10] * p.z + a[11];
+        mag = fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(L.body);
     }
-    // yaw limits: angle = atan2f(ay, ax) with ax >= 0, limits inside (-pi/2, pi/2)
-    const float band_c = LRM_BAND * (ax + fabsf(ay));
-    const bool above = lrm_dir_gt(ax, ay, L.max_coxa, L.dir_cos[3], L.dir_sin[3], band_c, unc);
-    // angle < min  <=>  not (angle > min) and angle != min; equality sits inside the band
-    const bool not_below = lrm_dir_gt(ax, ay, L.min_coxa, L.dir_cos[4], L.dir_sin[4], band_c, unc);
-    if (above || !not_below) return false;
-    const float S = fabsf(px) + fabsf(p.z) + L.fast_scale + 2.0f * r_xy;
-    const float band = LRM_BAND * S;
-    const int reg = lrm_region_fast(L, px, p.z, band, unc);
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < LRM_N_CIRCLES; i++)
-        ok = ok & lrm_valid_fast(lists[reg * LRM_N_CIRCLES + i], flists[reg * LRM_N_CIRCLES + i], px, p.z, band, unc);
-    return ok;
+    // the strict chain (qtRotate, z rotation, translation, pitch rotation) stays within ~17u*mag of
+    // the true coxa-frame point and this map within ~5u*mag: 22u*mag = 1.3e-6*mag apart at most;
+    // LRM_BAND * 1.5 * mag = 6e-6*mag covers it 4.5 times
+    return lrm_reach_coxa_lean(L, lean, x, y, z, 1.5f * mag, unc);
 }
 
-LRM_HD bool lrm_reach_global_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
-                                  const LrmCompiledLeg::FastCircle* flists, LrmVec3 p, uint32_t& unc) {
-    LrmVec3 u = lrm_qrot(L.inv_rot, p);
-    const float buffer = u.x * L.sin_body;
-    u.x = u.x * L.cos_body - u.y * L.sin_body;
-    u.y = buffer + u.y * L.cos_body;
-    // non-finite coordinates: every band test above fails closed (NaN compares false)
-    return lrm_reach_circles_fast(L, lists, flists, u, unc);
-}
-
-LRM_HD bool lrm_reachable_rotate_leg_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
-                                          const LrmCompiledLeg::FastCircle* flists, LrmVec3 t, LrmVec3 body,
-                                          uint32_t& unc) {
-    t.x -= body.x;
+LRM_HD bool lrm_reachable_rotate_leg_fast(const LrmCompiledLeg& L, const LrmCompiledLeg::LeanCircle* lean,
+                                          LrmVec3 t, LrmVec3 body, uint32_t& unc) {
+    t.x -= body.x; // same float subtractions as the strict code
     t.y -= body.y;
     t.z -= body.z;
-    const LrmVec3 g = lrm_qrot(L.inv_rot, t);
-    const float gx = g.x * L.cos_body - g.y * L.sin_body;
-    if (gx < 0) return false;
-    const float buffer = t.x * L.sin_body;
-    t.x = t.x * L.cos_body - t.y * L.sin_body;
-    t.y = buffer + t.y * L.cos_body;
-    return lrm_reach_circles_fast(L, lists, flists, t, unc);
+    float x, y, z, gx, mag;
+    {
+#pragma clang fp contract(fast)
+        const float* a = L.aff_pair;
+        mag = fabsf(t.x) + fabsf(t.y) + fabsf(t.z);
+        gx = L.grav_row[0] * t.x + L.grav_row[1] * t.y + L.grav_row[2] * t.z;
+        x = a[0] * t.x + a[1] * t.y + a[2] * t.z + a[3];
+        y = a[4] * t.x + a[5] * t.y + a[6] * t.z + a[7];
+        z = a[8] * t.x + a[9] * t.y + a[10] * t.z + a[11];
+    }
+    // gravity side (several_leg.cu:58-61): strict gx < 0 -> not reachable
+    const float gband = 1.5f * LRM_BAND * mag;
+    unc |= !(fabsf(gx) > gband) ? 2u : 0u;
+    if (gx < 0.f) return false;
+    return lrm_reach_coxa_lean(L, lean, x, y, z, 1.5f * (mag + fabsf(L.body)), unc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -342,18 +381,17 @@ LRM_HD bool lrm_dist_global_fast(const LrmCompiledLeg& L, const LrmCircle* lists
 // the strict result bit for bit whatever the bands decide.
 // ---------------------------------------------------------------------------------------
 LRM_HD bool lrm_reach_global_filtered(const LrmCompiledLeg& L, const LrmCircle* lists,
-                                      const LrmCompiledLeg::FastCircle* flists, LrmVec3 p) {
+                                      const LrmCompiledLeg::LeanCircle* lean, LrmVec3 p) {
     uint32_t unc = 0;
-    bool r = lrm_reach_global_fast(L, lists, flists, p, unc);
+    bool r = lrm_reach_global_fast(L, lean, p, unc);
     if (unc) r = lrm_reach_global(L, lists, p);
     return r;
 }
 
 LRM_HD bool lrm_reachable_rotate_leg_filtered(const LrmCompiledLeg& L, const LrmCircle* lists,
-                                              const LrmCompiledLeg::FastCircle* flists, LrmVec3 t,
-                                              LrmVec3 body) {
+                                              const LrmCompiledLeg::LeanCircle* lean, LrmVec3 t, LrmVec3 body) {
     uint32_t unc = 0;
-    bool r = lrm_reachable_rotate_leg_fast(L, lists, flists, t, body, unc);
+    bool r = lrm_reachable_rotate_leg_fast(L, lean, t, body, unc);
     if (unc) r = lrm_reachable_rotate_leg(L, lists, t, body);
     return r;
 }

@@ -62,4 +62,16 @@ struct LrmCompiledLeg {
     float ucorner_x[LRM_N_CORNERS];
     float ucorner_y[LRM_N_CORNERS];
     float pad_[1];
+    // ---- lean reach filter (lrm_point_fast.h): everything below is decision-only data ----
+    // body-frame point -> coxa frame in one affine map (row-major 3x4, FMA-evaluated):
+    //   global: Rp * (Rz * (Rq * p) - (body,0,0));   pair: Rp * (Rz * t - (body,0,0)), t = target - body
+    float aff_global[12];
+    float aff_pair[12];
+    float grav_row[3];                  // x row of Rz * Rq: the "gravity side" test of reachable_rotate_leg
+    float pad2_[1];
+    // one 16-byte record per circle of a list: valid <=> (m - T) * gs < 0, |(m - T) * gs| = distance to the
+    // decision boundary in mm (gs = sg / (2 (r + margin)))
+    struct LeanCircle {
+        float x, y, T, gs;
+    } lean[4][LRM_N_CIRCLES];
 };
