@@ -295,9 +295,21 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
                 auto& q = out->lean[k][i];
                 q.x = out->lists[k][i].x;
                 q.y = out->lists[k][i].y;
-                q.T = out->flists[k][i].T;
-                q.gs = (float)((double)out->flists[k][i].sg / (double)out->flists[k][i].g);
+                const double gs = (double)out->flists[k][i].sg / (double)out->flists[k][i].g;
+                q.gs = (float)gs;
+                q.c = (float)(-(double)out->flists[k][i].T * gs);
             }
+    }
+
+    // One band for every test of the lean reach filter, linear in the L1 size of the input
+    // point: the coxa-frame coordinates obey |x|+|y|+|z| <= sqrt(3) (|p|_1 + body), the affine map
+    // is within 22u (|p|_1 + body) of the strict chain, the hardware sqrt within 8u r:
+    //   S = fast_scale + (sqrt(3) + 1.5) (|p|_1 + body),  band = LRM_BAND * S.
+    {
+        const double kBand = 4.0e-6; // LRM_BAND (lrm_point_fast.h)
+        const double slope = 1.7320508 + 1.5;
+        out->band_base = (float)(kBand * ((double)out->fast_scale + slope * std::fabs((double)l.body)));
+        out->band_slope = (float)(kBand * slope);
     }
 
     // Nothing farther than the stretched leg (+1 mm and 1e-4 relative slack, three orders of

@@ -82,72 +82,64 @@ LRM_HD bool lrm_valid_fast(const LrmCircle c, const LrmCompiledLeg::FastCircle f
 // compare/select chains: v_max / v_min accumulators.
 // ---------------------------------------------------------------------------------------
 
-// "atan2f(y, x) > C" from the cross product t = cosC*y - sinC*x (see lrm_dir_gt)
+// "atan2f(y, x) > C" from the cross product t = cosC*y - sinC*x (see lrm_dir_gt); branch-free:
+// C >= 0: t > 0 and y >= 0;  C < 0: y >= 0 or t > 0
 LRM_HD bool lrm_gt_from_t(float t, bool ypos, bool c_nonneg) {
     const bool tp = t > 0.f;
-    return c_nonneg ? (tp && ypos) : (ypos || tp);
+    return (tp & ypos) | ((!c_nonneg) & (tp | ypos));
 }
 
-// (x, y, z): the point in the coxa frame (after place_over_coxa), possibly approximate with an
-// absolute error covered by `extra` (mm, before the LRM_BAND factor).
+// (x, y, z): the point in the coxa frame (after place_over_coxa), approximate; `band` (mm) covers
+// the distance between this evaluation and the strict one for every test below.
 LRM_HD bool lrm_reach_coxa_lean(const LrmCompiledLeg& L, const LrmCompiledLeg::LeanCircle* lean, float x, float y,
-                                float z, float extra, uint32_t& unc) {
-#pragma clang fp contract(fast)
+                                float z, float band, uint32_t& unc) {
     const uint32_t sx = lrm_f2u(x) & 0x80000000u;
     const float ax = fabsf(x);
     const float ay = lrm_u2f(lrm_f2u(y) ^ sx); // the reference mirrors the point into x >= 0 (one_leg.cu:291-296)
-    const float r_xy = LRM_FAST_SQRT(ax * ax + ay * ay);
+    const float r_xy = LRM_FAST_SQRT(__builtin_fmaf(ay, ay, ax * ax));
     const float px = lrm_u2f(lrm_f2u(r_xy) | sx) - L.coxa_length;
-    const float S = L.fast_scale + (ax + fabsf(ay) + fabsf(z)) + extra; // r_xy: 8u*r << LRM_BAND*r
-    const float band = LRM_BAND * S;
     // yaw limits (both inside (-pi/2, pi/2), ax >= 0): above <=> t_max > 0, below <=> t_min < 0
-    const float t_max = L.dir_cos[3] * ay - L.dir_sin[3] * ax;
-    const float t_min = L.dir_cos[4] * ay - L.dir_sin[4] * ax;
+    const float t_max = __builtin_fmaf(L.dir_cos[3], ay, -(L.dir_sin[3] * ax));
+    const float t_min = __builtin_fmaf(L.dir_cos[4], ay, -(L.dir_sin[4] * ax));
     const float coxa_v = fmaxf(t_max, -t_min);
     const float coxa_m = fminf(fabsf(t_max), fabsf(t_min));
     // region (circles.cu.h:48-78)
-    const float t_mid = L.dir_cos[0] * z - L.dir_sin[0] * px;
-    const float t_s0 = L.dir_cos[1] * z - L.dir_sin[1] * px;
-    const float t_s1 = L.dir_cos[2] * z - L.dir_sin[2] * px;
+    const float t_mid = __builtin_fmaf(L.dir_cos[0], z, -(L.dir_sin[0] * px));
+    const float t_s0 = __builtin_fmaf(L.dir_cos[1], z, -(L.dir_sin[1] * px));
+    const float t_s1 = __builtin_fmaf(L.dir_cos[2], z, -(L.dir_sin[2] * px));
     const bool ypos = !(lrm_f2u(z) >> 31);
     const bool upper = lrm_gt_from_t(t_mid, ypos, L.region_mid >= 0.f);
     const bool more0 = lrm_gt_from_t(t_s0, ypos, L.full_sat[0] >= 0.f);
     const bool more1 = lrm_gt_from_t(t_s1, ypos, L.full_sat[1] >= 0.f);
-    const bool more = upper ? more1 : more0;
-    const int reg = (upper ? 2 : 0) + ((upper != more) ? 1 : 0);
+    const bool more = (upper & more1) | ((!upper) & more0);
+    const bool fe = upper != more;
     // doubt of the region: distance to any of the three rays, or to the atan2f wrap ray (x < 0, y = +-0)
     float macc = fminf(fminf(fabsf(t_mid), fabsf(t_s0)), fminf(fabsf(t_s1), fmaxf(px, fabsf(z))));
-    const LrmCompiledLeg::LeanCircle* c = lean + reg * LRM_N_CIRCLES;
+    const LrmCompiledLeg::LeanCircle* c = lean + ((upper ? 8 : 0) + (fe ? 4 : 0));
     float vacc = -3.0e38f;
 #pragma unroll
     for (int i = 0; i < LRM_N_CIRCLES; i++) {
         const LrmCompiledLeg::LeanCircle ci = c[i];
         const float dx = px - ci.x, dy = z - ci.y;
-        const float v = (dx * dx + dy * dy - ci.T) * ci.gs;
+        const float v = __builtin_fmaf(__builtin_fmaf(dy, dy, dx * dx), ci.gs, ci.c);
         vacc = fmaxf(vacc, v);
         macc = fminf(macc, fabsf(v));
     }
     const bool coxa_ok = coxa_v < 0.f;
     // outside the yaw range the answer is "no" whatever the circles say
-    unc |= (!(coxa_m > band) || (coxa_ok && !(macc > band))) ? 1u : 0u;
-    return coxa_ok && (vacc < 0.f);
+    unc |= ((!(coxa_m > band)) | (coxa_ok & !(macc > band))) ? 1u : 0u;
+    return coxa_ok & (vacc < 0.f);
 }
 
 LRM_HD bool lrm_reach_global_fast(const LrmCompiledLeg& L, const LrmCompiledLeg::LeanCircle* lean, LrmVec3 p,
                                   uint32_t& unc) {
-    float x, y, z, mag;
-    {
-#pragma clang fp contract(fast)
-        const float* a = L.aff_global;
-        x = a[0] * p.x + a[1] * p.y + a[2] * p.z + a[3];
-        y = a[4] * p.x + a[5] * p.y + a[6] * p.z + a[7];
-        z = a[8] * p.x + a[9] * p.y + a[10] * p.z + a[11];
-        mag = fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(L.body);
-    }
-    // the strict chain (qtRotate, z rotation, translation, pitch rotation) stays within ~17u*mag of
-    // the true coxa-frame point and this map within ~5u*mag: 22u*mag = 1.3e-6*mag apart at most;
-    // LRM_BAND * 1.5 * mag = 6e-6*mag covers it 4.5 times
-    return lrm_reach_coxa_lean(L, lean, x, y, z, 1.5f * mag, unc);
+    const float* a = L.aff_global;
+    const float x = __builtin_fmaf(a[0], p.x, __builtin_fmaf(a[1], p.y, __builtin_fmaf(a[2], p.z, a[3])));
+    const float y = __builtin_fmaf(a[4], p.x, __builtin_fmaf(a[5], p.y, __builtin_fmaf(a[6], p.z, a[7])));
+    const float z = __builtin_fmaf(a[8], p.x, __builtin_fmaf(a[9], p.y, __builtin_fmaf(a[10], p.z, a[11])));
+    // non-finite input: the band is nan/inf and every "> band" test fails closed
+    const float band = __builtin_fmaf(fabsf(p.x) + fabsf(p.y) + fabsf(p.z), L.band_slope, L.band_base);
+    return lrm_reach_coxa_lean(L, lean, x, y, z, band, unc);
 }
 
 LRM_HD bool lrm_reachable_rotate_leg_fast(const LrmCompiledLeg& L, const LrmCompiledLeg::LeanCircle* lean,
@@ -155,21 +147,17 @@ LRM_HD bool lrm_reachable_rotate_leg_fast(const LrmCompiledLeg& L, const LrmComp
     t.x -= body.x; // same float subtractions as the strict code
     t.y -= body.y;
     t.z -= body.z;
-    float x, y, z, gx, mag;
-    {
-#pragma clang fp contract(fast)
-        const float* a = L.aff_pair;
-        mag = fabsf(t.x) + fabsf(t.y) + fabsf(t.z);
-        gx = L.grav_row[0] * t.x + L.grav_row[1] * t.y + L.grav_row[2] * t.z;
-        x = a[0] * t.x + a[1] * t.y + a[2] * t.z + a[3];
-        y = a[4] * t.x + a[5] * t.y + a[6] * t.z + a[7];
-        z = a[8] * t.x + a[9] * t.y + a[10] * t.z + a[11];
-    }
+    const float* a = L.aff_pair;
+    const float mag = fabsf(t.x) + fabsf(t.y) + fabsf(t.z);
+    const float gx = __builtin_fmaf(L.grav_row[0], t.x, __builtin_fmaf(L.grav_row[1], t.y, L.grav_row[2] * t.z));
+    const float band = __builtin_fmaf(mag, L.band_slope, L.band_base);
     // gravity side (several_leg.cu:58-61): strict gx < 0 -> not reachable
-    const float gband = 1.5f * LRM_BAND * mag;
-    unc |= !(fabsf(gx) > gband) ? 2u : 0u;
+    unc |= !(fabsf(gx) > band) ? 2u : 0u;
     if (gx < 0.f) return false;
-    return lrm_reach_coxa_lean(L, lean, x, y, z, 1.5f * (mag + fabsf(L.body)), unc);
+    const float x = __builtin_fmaf(a[0], t.x, __builtin_fmaf(a[1], t.y, __builtin_fmaf(a[2], t.z, a[3])));
+    const float y = __builtin_fmaf(a[4], t.x, __builtin_fmaf(a[5], t.y, __builtin_fmaf(a[6], t.z, a[7])));
+    const float z = __builtin_fmaf(a[8], t.x, __builtin_fmaf(a[9], t.y, __builtin_fmaf(a[10], t.z, a[11])));
+    return lrm_reach_coxa_lean(L, lean, x, y, z, band, unc);
 }
 
 // ---------------------------------------------------------------------------------------

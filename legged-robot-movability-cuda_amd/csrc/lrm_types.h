@@ -15,7 +15,7 @@
 
 // Circle, HeaderCPP.h:9-15, widened to 16 B so that one ds_read_b128 fetches it.
 // attract: 1.0f = the point must lie inside, 0.0f = outside.
-struct LrmCircle {
+struct alignas(16) LrmCircle {
     float x, y, r, attract;
 };
 
@@ -50,7 +50,7 @@ struct LrmCompiledLeg {
     // squared-domain validity test of circle lists[k][i]:  valid <=> sg*(m - T) < 0 with
     // m = |p - c|^2;  T = (r + margin)^2, sg = +1 (attractive) or T = (r - margin)^2, sg = -1;
     // g = 2*(r + margin) converts a distance band into a band on m.
-    struct FastCircle {
+    struct alignas(16) FastCircle {
         float T, sg, g, pad;
     } flists[4][LRM_N_CIRCLES];
     // direction tests "angle > C" as cross products: (cos C, sin C) for
@@ -69,9 +69,11 @@ struct LrmCompiledLeg {
     float aff_pair[12];
     float grav_row[3];                  // x row of Rz * Rq: the "gravity side" test of reachable_rotate_leg
     float pad2_[1];
-    // one 16-byte record per circle of a list: valid <=> (m - T) * gs < 0, |(m - T) * gs| = distance to the
-    // decision boundary in mm (gs = sg / (2 (r + margin)))
-    struct LeanCircle {
-        float x, y, T, gs;
+    // one 16-byte record per circle of a list: v = m * gs + c with m = |p - centre|^2,
+    // gs = sg / (2 (r + margin)), c = -T * gs: the point is valid <=> v < 0, and |v| is its
+    // distance (mm) to that decision boundary
+    struct alignas(16) LeanCircle {
+        float x, y, gs, c;
     } lean[4][LRM_N_CIRCLES];
+    float band_base, band_slope;        // band = band_base + band_slope * (|px| + |py| + |pz|), see lrm_point_fast.h
 };
