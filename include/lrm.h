@@ -142,12 +142,15 @@ int lrm_reach_any_dev(const float* bx, const float* by, const float* bz, size_t 
                       const float* tx, const float* ty, const float* tz, size_t nt,
                       const LrmLegDimensions* legs, size_t nlegs, const float* quat,
                       uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream);
-/* host-buffer form (AoS in, as robot_full_struct's Array<float3> arguments,
- * several_leg.cu:796-808); quats is nquat x 4; body_mask_out[b] = 1 iff for SOME
- * orientation EVERY leg (limits rotated per orientation) has a reachable target. */
+/* host-buffer form of robot_full_struct's pipeline (several_leg.cu:326-877; AoS in, as its
+ * Array<float3> arguments); quats is nquat x 4; body_mask_out[b] = 1 iff for SOME orientation
+ * EVERY leg (limits rotated per orientation, bodies and targets rotated by the quaternion) has a
+ * reachable target.  reference_culls != 0 additionally applies multi_rot_estimator's culls: the
+ * one-time spheres (r = 60 collision, r = 400 far body / far target, :413-502) and the
+ * per-orientation cylinder pair of eliminateFarAndColliding (:504-559).  *ms = kernel time. */
 int lrm_positionability(const float* bodies_aos, size_t nb, const float* targets_aos, size_t nt,
                         const LrmLegDimensions* legs, size_t nlegs, const float* quats,
-                        size_t nquat, uint8_t* body_mask_out, float* ms);
+                        size_t nquat, int reference_culls, uint8_t* body_mask_out, float* ms);
 
 /* in_sphere / in_cylinder any-reductions: launch_optimized_mem_in_sphere /
  * launch_optimized_mem_in_cylinder (collision.cu:68-98, :148-168):

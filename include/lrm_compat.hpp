@@ -115,8 +115,9 @@ inline LegDimensions get_moonbot_leg(float body_angle) {
 // robot_full_struct, several_leg.cu:796-877: orientation sweep roll(3) x pitch(3) x yaw(5)
 // (quat = yaw * pitch * roll, several_leg.cu:831-857); returns the accepted bodies and the
 // reference's dummy count array (filled with 3, several_leg.cu:868); both new[]-ed, owned by
-// the caller.  The reference's one-time sphere culls (several_leg.cu:413-502) and per-
-// orientation cylinder culls (:504-559) are not applied here (scope).
+// the caller.  The estimator's one-time sphere culls (several_leg.cu:413-502) and per-orientation
+// cylinder culls (:504-559) are applied; accepted bodies come back in input order (the reference's
+// thrust::partition leaves them in an unspecified order).
 inline std::tuple<Array<float3>, Array<int>> robot_full_struct(Array<float3> body_map, Array<float3> target_map,
                                                                Array<LegDimensions> legs) {
     // orientation list with the reference's own quaternion helpers, restated
@@ -154,7 +155,7 @@ inline std::tuple<Array<float3>, Array<int>> robot_full_struct(Array<float3> bod
     float ms = 0.f;
     lrm_compat_detail::check(lrm_positionability(&body_map.elements->x, body_map.length, &target_map.elements->x,
                                                  target_map.length, legs.elements, legs.length, quats.data(),
-                                                 quats.size() / 4, accepted.data(), &ms),
+                                                 quats.size() / 4, /*reference_culls=*/1, accepted.data(), &ms),
                              "robot_full_struct");
     size_t n = 0;
     for (uint8_t a : accepted) n += a;

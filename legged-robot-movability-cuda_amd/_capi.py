@@ -72,7 +72,7 @@ def load():
         "lrm_reach_aos_dev": [vp, sz, vp, vp, vp, vp],
         "lrm_dist_aos_dev": [vp, sz, vp, vp, vp, vp, vp],
         "lrm_reach_any_dev": [vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp],
-        "lrm_positionability": [vp, sz, vp, sz, vp, sz, vp, sz, vp, vp],
+        "lrm_positionability": [vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, vp, vp],
         "lrm_dbg_fast_host": [vp, sz, vp, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
         "lrm_dbg_exact_math_dev": [vp, vp, sz, vp, vp, vp, vp],
@@ -220,8 +220,8 @@ def dbg_fast_host(xyz, leg, quat=None):
     return out
 
 
-def positionability(bodies, targets, legs, quats):
-    """robot_full_struct's result as a mask (several_leg.cu:796-877) -> (uint8[nb], ms); GPU."""
+def positionability(bodies, targets, legs, quats, reference_culls=False):
+    """robot_full_struct's pipeline as a mask (several_leg.cu:326-877) -> (uint8[nb], ms); GPU."""
     bodies = _f32(bodies, (-1, 3))
     targets = _f32(targets, (-1, 3))
     legs = _f32(legs).reshape(-1, 14)
@@ -229,5 +229,6 @@ def positionability(bodies, targets, legs, quats):
     out = np.zeros(len(bodies), np.uint8)
     ms = C.c_float(0)
     check(load().lrm_positionability(_ptr(bodies), len(bodies), _ptr(targets), len(targets), _ptr(legs),
-                                     len(legs), _ptr(quats), len(quats), _ptr(out), C.addressof(ms)))
+                                     len(legs), _ptr(quats), len(quats), int(bool(reference_culls)), _ptr(out),
+                                     C.addressof(ms)))
     return out, ms.value

@@ -343,63 +343,148 @@ int lrm_dbg_fast_host(const float* xyz, size_t n, const LrmLegDimensions* leg, c
     return LRM_OK;
 }
 
-// robot_full_struct's core (several_leg.cu:796-877) as a mask: for each orientation the legs'
-// limits are rotated on the host (several_leg.cu:743-760), bodies AND targets are rotated by the
-// quaternion (rotateData, several_leg.cu:401-411) -- done here on the host copies -- and
-// every leg must find a target; a body is accepted by the first orientation that succeeds.
+// robot_full_struct's pipeline (several_leg.cu:326-877) with masks instead of thrust stream
+// compaction.  reference_culls != 0 adds the estimator's culls:
+//   once      eliminateAlwaysColliding (sphere r = 60, :413-440), eliminateFarBody (r = 400, :442-474),
+//             eliminateFarTarget (r = 400 around the surviving bodies, :476-502)
+//   per quat  eliminateFarAndColliding (:504-559): keep a body iff some target lies in the big
+//             cylinder of (rotated) leg 0 and none in the body cylinder (r = body, z in (-110, 250))
+// For each orientation bodies and targets are rotated by the quaternion (rotateData :401-411, on
+// the host copies here), the legs' limits are rotated (rotateLegsLimits :743-760), every leg must
+// find a reachable target (eliminateUnreachable :707-741, generalised from 4 to nlegs legs), and a
+// body accepted by one orientation is not tested again (flipWorkingSide :396-399).
 int lrm_positionability(const float* bodies, size_t nb, const float* targets, size_t nt,
                         const LrmLegDimensions* legs, size_t nlegs, const float* quats, size_t nquat,
-                        uint8_t* body_mask_out, float* ms) {
+                        int reference_culls, uint8_t* body_mask_out, float* ms) {
     if (!legs || nlegs == 0 || nlegs > LRM_MAX_LEGS) return fail(LRM_EINVAL, "nlegs must be 1..LRM_MAX_LEGS");
     if ((nb && (!bodies || !body_mask_out)) || (nt && !targets) || (nquat && !quats))
         return fail(LRM_EINVAL, "null argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LRM_ENODEV, "no HIP device");
     if (nb == 0) return LRM_OK;
-    std::vector<float> hb(3 * nb), ht(3 * (nt ? nt : 1));
-    DevBuf d_b, d_t, d_leg_body, d_all, d_acc;
-    HIP_TRY(d_b.alloc(3 * nb * sizeof(float)), "hipMalloc bodies");
-    HIP_TRY(d_t.alloc(3 * nt * sizeof(float)), "hipMalloc targets");
-    HIP_TRY(d_leg_body.alloc(nlegs * nb), "hipMalloc leg results");
-    HIP_TRY(d_all.alloc(nb), "hipMalloc body results");
-    std::vector<uint8_t> acc(nb, 0), cur(nb);
+    std::memset(body_mask_out, 0, nb);
+    float total_ms = 0.f;
     Events ev;
     HIP_TRY(hipEventCreate(&ev.a), "hipEventCreate");
     HIP_TRY(hipEventCreate(&ev.b), "hipEventCreate");
-    float total_ms = 0.f;
-    for (size_t qi = 0; qi < nquat; qi++) {
+    DevBuf d_b, d_t, d_m1, d_m2, d_leg_body, d_all;
+    HIP_TRY(d_b.alloc(3 * nb * sizeof(float)), "hipMalloc bodies");
+    HIP_TRY(d_t.alloc(3 * (nt + nb) * sizeof(float)), "hipMalloc targets");
+    HIP_TRY(d_m1.alloc(nb > nt ? nb : nt), "hipMalloc mask");
+    HIP_TRY(d_m2.alloc(nb > nt ? nb : nt), "hipMalloc mask");
+    HIP_TRY(d_leg_body.alloc(nlegs * nb), "hipMalloc leg results");
+    HIP_TRY(d_all.alloc(nb), "hipMalloc body results");
+
+    // SoA upload helper: idx selects rows of an AoS array (optionally rotated by rot's fwd_rot)
+    std::vector<float> stage;
+    auto upload = [&](const float* aos, const std::vector<size_t>& idx, const LrmCompiledLeg* rot, void* dst) -> hipError_t {
+        const size_t m = idx.size();
+        stage.resize(3 * (m ? m : 1));
+        for (size_t k = 0; k < m; k++) {
+            LrmVec3 v{aos[3 * idx[k]], aos[3 * idx[k] + 1], aos[3 * idx[k] + 2]};
+            if (rot) v = lrm_qrot(rot->fwd_rot, v);
+            stage[k] = v.x; stage[m + k] = v.y; stage[2 * m + k] = v.z;
+        }
+        return hipMemcpy(dst, stage.data(), 3 * m * sizeof(float), hipMemcpyHostToDevice);
+    };
+    std::vector<uint8_t> h1(nb > nt ? nb : nt), h2(nb > nt ? nb : nt);
+    std::vector<size_t> active(nb), kept_t(nt);
+    for (size_t i = 0; i < nb; i++) active[i] = i;
+    for (size_t i = 0; i < nt; i++) kept_t[i] = i;
+
+    if (reference_culls && nt) {
+        HIP_TRY(upload(bodies, active, nullptr, d_b.p), "hipMemcpy bodies");
+        HIP_TRY(upload(targets, kept_t, nullptr, d_t.p), "hipMemcpy targets");
+        const float* B = d_b.as<float>();
+        const float* T = d_t.as<float>();
+        HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
+        int rc = lrm_any_in_sphere_dev(B, B + nb, B + 2 * nb, nb, T, T + nt, T + 2 * nt, nt, 60.f, d_m1.as<uint8_t>(), nullptr);
+        if (rc == LRM_OK) rc = lrm_any_in_sphere_dev(B, B + nb, B + 2 * nb, nb, T, T + nt, T + 2 * nt, nt, 400.f, d_m2.as<uint8_t>(), nullptr);
+        if (rc != LRM_OK) return rc;
+        HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
+        HIP_TRY(hipMemcpy(h1.data(), d_m1.p, nb, hipMemcpyDeviceToHost), "hipMemcpy mask");
+        HIP_TRY(hipMemcpy(h2.data(), d_m2.p, nb, hipMemcpyDeviceToHost), "hipMemcpy mask");
+        float e = 0.f;
+        HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
+        total_ms += e;
+        std::vector<size_t> alive;
+        for (size_t i = 0; i < nb; i++)
+            if (h1[i] == 0 && h2[i] != 0) alive.push_back(i);
+        active.swap(alive);
+        // eliminateFarTarget: targets with a surviving body within 400
+        if (!active.empty()) {
+            const size_t na = active.size();
+            HIP_TRY(upload(bodies, active, nullptr, d_b.p), "hipMemcpy bodies");
+            const float* A = d_b.as<float>();
+            HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
+            rc = lrm_any_in_sphere_dev(T, T + nt, T + 2 * nt, nt, A, A + na, A + 2 * na, na, 400.f, d_m1.as<uint8_t>(), nullptr);
+            if (rc != LRM_OK) return rc;
+            HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
+            HIP_TRY(hipMemcpy(h1.data(), d_m1.p, nt, hipMemcpyDeviceToHost), "hipMemcpy mask");
+            HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
+            total_ms += e;
+            std::vector<size_t> kt;
+            for (size_t i = 0; i < nt; i++)
+                if (h1[i]) kt.push_back(i);
+            kept_t.swap(kt);
+        } else {
+            kept_t.clear();
+        }
+    }
+
+    for (size_t qi = 0; qi < nquat && !active.empty(); qi++) {
         const float* q = quats + 4 * qi;
         LrmCompiledLeg rot;
         LrmLegDimensions dummy{};
         lrm_compile_leg(dummy, q, 0, &rot); // only for fwd_rot = qtRotate(q, .)
         LrmLegDimensions rl[LRM_MAX_LEGS];
         for (size_t l = 0; l < nlegs; l++) lrm_host_rotate_leg_data(q, legs[l], &rl[l]);
-        // SoA staging of the rotated clouds: [x.. | y.. | z..]
-        for (size_t i = 0; i < nb; i++) {
-            const LrmVec3 r = lrm_qrot(rot.fwd_rot, LrmVec3{bodies[3 * i], bodies[3 * i + 1], bodies[3 * i + 2]});
-            hb[i] = r.x; hb[nb + i] = r.y; hb[2 * nb + i] = r.z;
-        }
-        for (size_t i = 0; i < nt; i++) {
-            const LrmVec3 r = lrm_qrot(rot.fwd_rot, LrmVec3{targets[3 * i], targets[3 * i + 1], targets[3 * i + 2]});
-            ht[i] = r.x; ht[nt + i] = r.y; ht[2 * nt + i] = r.z;
-        }
-        HIP_TRY(hipMemcpy(d_b.p, hb.data(), 3 * nb * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy bodies");
-        if (nt) HIP_TRY(hipMemcpy(d_t.p, ht.data(), 3 * nt * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy targets");
-        HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
+        const size_t na = active.size(), mt = kept_t.size();
+        HIP_TRY(upload(bodies, active, &rot, d_b.p), "hipMemcpy bodies");
+        HIP_TRY(upload(targets, kept_t, &rot, d_t.p), "hipMemcpy targets");
         const float* B = d_b.as<float>();
         const float* T = d_t.as<float>();
-        int rc = lrm_reach_any_dev(B, B + nb, B + 2 * nb, nb, T, T + nt, T + 2 * nt, nt, rl, nlegs, q,
-                                   d_leg_body.as<uint8_t>(), d_all.as<uint8_t>(), nullptr);
+        HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
+        int rc = LRM_OK;
+        if (reference_culls) {
+            // eliminateFarAndColliding, several_leg.cu:504-525, with the rotated leg 0
+            const LrmLegDimensions& d = rl[0];
+            const float s_pitch = sinf(d.coxa_pitch), c_pitch = cosf(d.coxa_pitch);
+            const float radius_in = d.body + c_pitch * d.coxa_length + d.femur_length + d.tibia_length;
+            const float half_pi = 3.14159265358979323846264338327950288419716939937510582097f / 2;
+            const float plus_abs = d.tibia_length * sinf(d.tibia_absolute_pos) +
+                                   d.femur_length * sinf(half_pi < d.max_angle_femur ? half_pi : d.max_angle_femur);
+            const float plus_z_in = s_pitch * d.coxa_length + plus_abs;
+            const float minus_z_in = s_pitch * d.coxa_length - d.femur_length - d.tibia_length;
+            rc = lrm_any_in_cylinder_dev(B, B + na, B + 2 * na, na, T, T + mt, T + 2 * mt, mt, radius_in, plus_z_in,
+                                         minus_z_in, d_m1.as<uint8_t>(), nullptr);
+            if (rc == LRM_OK)
+                rc = lrm_any_in_cylinder_dev(B, B + na, B + 2 * na, na, T, T + mt, T + 2 * mt, mt, d.body, 250.f, -110.f,
+                                             d_m2.as<uint8_t>(), nullptr);
+            if (rc != LRM_OK) return rc;
+        }
+        rc = lrm_reach_any_dev(B, B + na, B + 2 * na, na, T, T + mt, T + 2 * mt, mt, rl, nlegs, q,
+                               d_leg_body.as<uint8_t>(), d_all.as<uint8_t>(), nullptr);
         if (rc != LRM_OK) return rc;
         HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
         HIP_TRY(hipEventSynchronize(ev.b), "reach_any");
         float e = 0.f;
         HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
         total_ms += e;
-        HIP_TRY(hipMemcpy(cur.data(), d_all.p, nb, hipMemcpyDeviceToHost), "hipMemcpy result");
-        for (size_t i = 0; i < nb; i++) acc[i] |= cur[i];
+        std::vector<uint8_t> acc(na);
+        HIP_TRY(hipMemcpy(acc.data(), d_all.p, na, hipMemcpyDeviceToHost), "hipMemcpy result");
+        if (reference_culls) {
+            HIP_TRY(hipMemcpy(h1.data(), d_m1.p, na, hipMemcpyDeviceToHost), "hipMemcpy mask");
+            HIP_TRY(hipMemcpy(h2.data(), d_m2.p, na, hipMemcpyDeviceToHost), "hipMemcpy mask");
+            for (size_t k = 0; k < na; k++) acc[k] = acc[k] && h1[k] == 1 && h2[k] != 1;
+        }
+        std::vector<size_t> rest;
+        for (size_t k = 0; k < na; k++) {
+            if (acc[k]) body_mask_out[active[k]] = 1;
+            else rest.push_back(active[k]);
+        }
+        active.swap(rest);
     }
-    std::memcpy(body_mask_out, acc.data(), nb);
     if (ms) *ms = total_ms;
     return LRM_OK;
 }

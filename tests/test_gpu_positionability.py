@@ -110,3 +110,56 @@ def test_any_in_sphere_and_cylinder(lrm, oracle, torch_cuda):
     assert np.array_equal(s.cpu().numpy().astype(bool), ws)
     assert np.array_equal(c.cpu().numpy().astype(bool), wc)
     assert 0 < ws.mean() < 1 and 0 < wc.mean() < 1
+
+
+def _any_in_sphere(centers, pts, radius):
+    d = centers[:, None, :] - pts[None, :, :]
+    return (np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]) < np.float32(radius)).any(1)
+
+
+def _any_in_cylinder(centers, pts, radius, plus_z, minus_z):
+    d = pts[None, :, :] - centers[:, None, :]
+    rad = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + np.float32(0)) < np.float32(radius)
+    return (rad & (d[..., 2] < np.float32(plus_z)) & (d[..., 2] > np.float32(minus_z))).any(1)
+
+
+def test_robot_full_struct_pipeline_with_reference_culls(lrm, oracle, torch_cuda):
+    """The estimator's pipeline (several_leg.cu:326-877) restated with numpy + the oracle: one-time
+    sphere culls, per-orientation cylinder culls on the rotated clouds with the rotated leg 0, all
+    legs reachable, first accepting orientation wins."""
+    rng = np.random.default_rng(31)
+    bodies, targets = scene(260, 2500, seed=13)
+    bodies[:, 2] = rng.uniform(-30, 700, len(bodies)).astype(np.float32)  # some collide, some are far
+    legs = np.stack([lrm.get_M2_leg(k * np.pi / 2) for k in range(4)])
+    f32 = np.float32
+    quats = [oracle.quat_from_vect_angle((0, 0, 1), 0.0)]
+    quats.append(oracle.qt_multiply(oracle.quat_from_vect_angle((0, 1, 0), -np.pi / 8), quats[0]))
+    quats.append(oracle.qt_multiply(oracle.quat_from_vect_angle((0, 0, 1), np.pi / 4), quats[1]))
+    got, ms = lrm.positionability(bodies, targets, legs, quats, reference_culls=True)
+    plain, _ = lrm.positionability(bodies, targets, legs, quats, reference_culls=False)
+
+    alive = ~_any_in_sphere(bodies, targets, 60.0) & _any_in_sphere(bodies, targets, 400.0)
+    kept = _any_in_sphere(targets, bodies[alive], 400.0)
+    want = np.zeros(len(bodies), np.uint8)
+    active = np.where(alive)[0]
+    tk = targets[kept]
+    for q in quats:
+        if len(active) == 0:
+            break
+        rb = np.stack([oracle.qt_rotate(q, b) for b in bodies[active]])
+        rt = np.stack([oracle.qt_rotate(q, t) for t in tk])
+        rl = np.stack([oracle.rotate_leg_data(q, l) for l in legs])
+        d = rl[0]
+        s_p, c_p = np.sin(d[2], dtype=f32), np.cos(d[2], dtype=f32)
+        radius_in = f32(f32(f32(d[1] + f32(c_p * d[3])) + d[5]) + d[4])
+        plus_abs = f32(f32(d[4] * np.sin(d[6], dtype=f32)) + f32(d[5] * np.sin(min(f32(np.pi) / f32(2), d[12]), dtype=f32)))
+        plus_z = f32(f32(s_p * d[3]) + plus_abs)
+        minus_z = f32(f32(f32(s_p * d[3]) - d[5]) - d[4])
+        ok = _any_in_cylinder(rb, rt, radius_in, plus_z, minus_z) & ~_any_in_cylinder(rb, rt, d[1], 250.0, -110.0)
+        ok &= oracle.reach_any(rb, rt, rl, q).min(axis=0).astype(bool)
+        want[active[ok]] = 1
+        active = active[~ok]
+    assert ms > 0
+    assert np.array_equal(got, want)
+    assert 0 < want.sum() < len(want)
+    assert (got <= plain).all() and (got != plain).any()  # the culls only remove bodies, and do remove some
