@@ -90,6 +90,15 @@ int lrm_dist(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const 
 int lrm_reach_dist(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                    uint8_t* mask_out, float* dxyz_aos_out, float* ms);
 
+/* Host buffers in the reference's on-disk layout: one f32 array per component, as
+ * dist_input_t{x,y,z}.bin / out_dist_x{x,y,z}.bin (several_leg.cpp:126-131, :201-219,
+ * math_util.cpp:46-89).  Same semantics as lrm_reach / lrm_dist without the AoS detour. */
+int lrm_reach_soa(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
+                  const float* quat, uint8_t* mask_out, float* ms);
+int lrm_dist_soa(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
+                 const float* quat, float* dx, float* dy, float* dz, uint8_t* valid_out /* may be NULL */,
+                 float* ms);
+
 /* ---- CPU path: apply_reach_cpu / apply_dist_cpu, cross_compiled.cu:163-181 -------------
  * Single-threaded host loops over the same per-point code the kernels run (the reference
  * compiles one `__host__ __device__` source twice in the same way).  These are explicit CPU

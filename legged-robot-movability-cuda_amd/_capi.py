@@ -62,6 +62,8 @@ def load():
         "lrm_reach": [vp, sz, vp, vp, vp, vp],
         "lrm_dist": [vp, sz, vp, vp, vp, vp, vp],
         "lrm_reach_dist": [vp, sz, vp, vp, vp, vp, vp],
+        "lrm_reach_soa": [vp, vp, vp, sz, vp, vp, vp, vp],
+        "lrm_dist_soa": [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp],
         "lrm_reach_cpu": [vp, sz, vp, vp, vp, vp],
         "lrm_dist_cpu": [vp, sz, vp, vp, vp, vp, vp],
         "lrm_reach_dev": [vp, vp, vp, sz, vp, vp, vp, vp],

@@ -141,6 +141,64 @@ int lrm_reach_dist(const float* xyz, size_t n, const LrmLegDimensions* leg, cons
     return host_apply(2, xyz, n, leg, quat, mask_out, dxyz_out, ms);
 }
 
+// Host buffers in the reference's ON-DISK layout (one f32 array per component,
+// several_leg.cpp:126-131, :201-219): straight to the SoA kernels, no AoS detour
+// (threeArrays2float3Arr, math_util.cpp:92, disappears).  op: 0 reach, 1 dist, 2 both.
+namespace {
+int host_apply_soa(int op, const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
+                   const float* quat, uint8_t* mask_out, float* dx, float* dy, float* dz, float* ms) {
+    if (!leg || (n && (!x || !y || !z))) return fail(LRM_EINVAL, "null input");
+    if ((op == 0 || op == 2) && n && !mask_out) return fail(LRM_EINVAL, "null mask output");
+    if ((op == 1 || op == 2) && n && (!dx || !dy || !dz)) return fail(LRM_EINVAL, "null distance output");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LRM_ENODEV, "no HIP device");
+    if (n == 0) { if (ms) *ms = 0.f; return LRM_OK; }
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    const size_t pad = (n + 3) & ~(size_t)3; // keeps the three component arrays 16-byte aligned
+    DevBuf d_in, d_mask, d_out;
+    HIP_TRY(d_in.alloc(3 * pad * sizeof(float)), "hipMalloc gpu_in.elements");
+    const bool want_mask = (op != 1) || mask_out;
+    if (want_mask) HIP_TRY(d_mask.alloc(n), "hipMalloc gpu_out.elements");
+    if (op != 0) HIP_TRY(d_out.alloc(3 * pad * sizeof(float)), "hipMalloc gpu_out.elements");
+    float* I = d_in.as<float>();
+    HIP_TRY(hipMemcpy(I, x, n * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy x");
+    HIP_TRY(hipMemcpy(I + pad, y, n * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy y");
+    HIP_TRY(hipMemcpy(I + 2 * pad, z, n * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy z");
+    HIP_TRY(lrm_launch_warmup(n, nullptr), "warm-up launch");
+    Events ev;
+    HIP_TRY(hipEventCreate(&ev.a), "hipEventCreate");
+    HIP_TRY(hipEventCreate(&ev.b), "hipEventCreate");
+    HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
+    const bool fast = g_mode == LRM_MODE_FAST;
+    float* O = d_out.as<float>();
+    if (op == 0) HIP_TRY(lrm_launch_reach_soa(I, I + pad, I + 2 * pad, n, L, d_mask.as<uint8_t>(), nullptr, fast, nullptr), "Kernel launch");
+    else HIP_TRY(lrm_launch_dist_soa(op, I, I + pad, I + 2 * pad, n, L, want_mask ? d_mask.as<uint8_t>() : nullptr, nullptr, O,
+                                     O + pad, O + 2 * pad, fast, nullptr), "Kernel launch");
+    HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
+    HIP_TRY(hipEventSynchronize(ev.b), "Kernel launch");
+    float elapsed = 0.f;
+    HIP_TRY(hipEventElapsedTime(&elapsed, ev.a, ev.b), "hipEventElapsedTime");
+    if (want_mask && mask_out) HIP_TRY(hipMemcpy(mask_out, d_mask.p, n, hipMemcpyDeviceToHost), "hipMemcpy mask");
+    if (op != 0) {
+        HIP_TRY(hipMemcpy(dx, O, n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy dx");
+        HIP_TRY(hipMemcpy(dy, O + pad, n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy dy");
+        HIP_TRY(hipMemcpy(dz, O + 2 * pad, n * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy dz");
+    }
+    if (ms) *ms = elapsed;
+    return LRM_OK;
+}
+} // namespace
+
+int lrm_reach_soa(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
+                  const float* quat, uint8_t* mask_out, float* ms) {
+    return host_apply_soa(0, x, y, z, n, leg, quat, mask_out, nullptr, nullptr, nullptr, ms);
+}
+int lrm_dist_soa(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
+                 const float* quat, float* dx, float* dy, float* dz, uint8_t* valid_out, float* ms) {
+    return host_apply_soa(1, x, y, z, n, leg, quat, valid_out, dx, dy, dz, ms);
+}
+
 // apply_reach_cpu / apply_dist_cpu (cross_compiled.cu:163-181): chrono-timed serial loops
 int lrm_reach_cpu(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
                   double* ms) {

@@ -129,12 +129,18 @@ def test_robot_full_struct_pipeline_with_reference_culls(lrm, oracle, torch_cuda
     legs reachable, first accepting orientation wins."""
     rng = np.random.default_rng(31)
     bodies, targets = scene(260, 2500, seed=13)
-    bodies[:, 2] = rng.uniform(-30, 700, len(bodies)).astype(np.float32)  # some collide, some are far
+    # gentle terrain (so that the body cylinder lets standing poses through) and body heights from
+    # colliding (< 60 mm) to hopeless (> 400 mm)
+    targets[:, 2] = (8 * np.sin(targets[:, 0] / 300) + rng.normal(0, 1.5, len(targets))).astype(np.float32)
+    bodies[:, 2] = rng.uniform(-30, 700, len(bodies)).astype(np.float32)
     legs = np.stack([lrm.get_M2_leg(k * np.pi / 2) for k in range(4)])
     f32 = np.float32
-    quats = [oracle.quat_from_vect_angle((0, 0, 1), 0.0)]
-    quats.append(oracle.qt_multiply(oracle.quat_from_vect_angle((0, 1, 0), -np.pi / 8), quats[0]))
-    quats.append(oracle.qt_multiply(oracle.quat_from_vect_angle((0, 0, 1), np.pi / 4), quats[1]))
+    # quaternions in qtRotate's own convention (scalar first, unified_math_cuda.cu.h:13): identity,
+    # 22.5 deg about y, 45 deg about z.  (quatFromVectAngle puts the sine in the scalar slot, so the
+    # reference's own sweep quaternions mean something else to qtRotate; they are covered by
+    # test_positionability_sweep_matches_bruteforce.)
+    quats = [(1, 0, 0, 0), (np.cos(np.pi / 16), 0, np.sin(np.pi / 16), 0), (np.cos(np.pi / 8), 0, 0, np.sin(np.pi / 8))]
+    quats = [np.asarray(q, np.float32) for q in quats]
     got, ms = lrm.positionability(bodies, targets, legs, quats, reference_culls=True)
     plain, _ = lrm.positionability(bodies, targets, legs, quats, reference_culls=False)
 
