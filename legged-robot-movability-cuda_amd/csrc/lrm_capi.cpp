@@ -390,7 +390,7 @@ int lrm_dbg_fast_host(const float* xyz, size_t n, const LrmLegDimensions* leg, c
         if (dxyz_out) {
             uint32_t unc = 0;
             LrmVec3 d = p;
-            const bool v = lrm_dist_global_fast(L, &L.lists[0][0], &L.flists[0][0], d, unc);
+            const bool v = lrm_dist_global_fast(L, LrmDistTables{&L.lists[0][0], &L.dist_tab[0][0], &L.corner_tab[0]}, d, unc);
             dxyz_out[3 * i] = d.x;
             dxyz_out[3 * i + 1] = d.y;
             dxyz_out[3 * i + 2] = d.z;

@@ -301,6 +301,31 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
             }
     }
 
+    // lean distance filter tables
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < LRM_N_CIRCLES; i++) {
+            auto& d = out->dist_tab[k][i];
+            const LrmCircle& ci = out->lists[k][i];
+            d.x = ci.x; d.y = ci.y; d.gs = out->lean[k][i].gs; d.c = out->lean[k][i].c;
+            d.r = ci.r; d.attract = ci.attract; d.pad0 = d.pad1 = 0.f;
+            int a = 0;
+            for (int j = 0; j < LRM_N_CIRCLES; j++) {
+                if (j == i) continue;
+                const LrmCircle& cj = out->lists[k][j];
+                const double ex = (double)ci.x - (double)cj.x, ey = (double)ci.y - (double)cj.y;
+                const double gsj = (double)out->flists[k][j].sg / (double)out->flists[k][j].g;
+                d.arc[a].ex = (float)ex;
+                d.arc[a].ey = (float)ey;
+                d.arc[a].P = (float)(2.0 * (double)ci.r * gsj);
+                d.arc[a].Q = (float)((ex * ex + ey * ey + (double)ci.r * (double)ci.r - (double)out->flists[k][j].T) * gsj);
+                a++;
+            }
+        }
+    for (int i = 0; i < LRM_N_CORNERS; i++)
+        out->corner_tab[i] = (i < out->n_ucorners) ? circle(out->ucorner_x[i], out->ucorner_y[i], 0.f, true)
+                                                   : circle(0.f, 0.f, 0.f, true);
+    out->band_q = (float)(4.0e-6 * 2.0 * (double)out->fast_scale);
+
     // One band for every test of the lean reach filter, linear in the L1 size of the input
     // point: the coxa-frame coordinates obey |x|+|y|+|z| <= sqrt(3) (|p|_1 + body), the affine map
     // is within 22u (|p|_1 + body) of the strict chain, the hardware sqrt within 8u r:

@@ -42,54 +42,53 @@ LRM_HD float lrm_u2f(uint32_t u) {
 #endif
 }
 
-// float atanf(float) -- FDLIBM s_atanf.c
+// float atanf(float) -- FDLIBM s_atanf.c, the five argument ranges evaluated through selects
+// instead of branches (a wave would otherwise walk all of them one after the other).  Every range
+// performs exactly the operations of the original in the original order:
+//   reduction  x' = (fl(A*|x|) - B) / (C + fl(D*|x|))  with (A,B,C,D) = (2,1,2,1), (1,1,1,1), (1,1.5,1,1.5);
+//   multiplying by 1.0f is exact, so the shared form changes no bit.
 LRM_HD float lrm_atanf(float x) {
-    const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f,
-                hi3 = 1.5707962513e+00f;
-    const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f,
-                lo3 = 7.5497894159e-08f;
     const float a0 = 3.3333334327e-01f, a1 = -2.0000000298e-01f, a2 = 1.4285714924e-01f,
                 a3 = -1.1111110449e-01f, a4 = 9.0908870101e-02f, a5 = -7.6918758452e-02f,
                 a6 = 6.6610731184e-02f, a7 = -5.8335702866e-02f, a8 = 4.9768779427e-02f,
                 a9 = -3.6531571299e-02f, a10 = 1.6285819933e-02f;
     const int32_t hx = (int32_t)lrm_f2u(x);
     const int32_t ix = hx & 0x7fffffff;
-    if (ix >= 0x4c000000) { // |x| >= 2^25
-        if (ix > 0x7f800000) return x + x;
-        return (hx > 0) ? hi3 + lo3 : -hi3 - lo3;
-    }
-    int id;
-    float hi = 0.f, lo = 0.f;
-    if (ix < 0x3ee00000) { // |x| < 0.4375
-        if (ix < 0x31000000) return x;
-        id = -1;
-    } else {
-        x = fabsf(x);
-        if (ix < 0x3f980000) {
-            if (ix < 0x3f300000) { id = 0; hi = hi0; lo = lo0; x = (2.0f * x - 1.0f) / (2.0f + x); }
-            else { id = 1; hi = hi1; lo = lo1; x = (x - 1.0f) / (x + 1.0f); }
-        } else {
-            if (ix < 0x401c0000) { id = 2; hi = hi2; lo = lo2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
-            else { id = 3; hi = hi3; lo = lo3; x = -1.0f / x; }
-        }
-    }
-    float z = x * x;
+    const float ax = fabsf(x);
+    const bool small = ix < 0x3ee00000; // |x| < 0.4375: no reduction
+    const bool r0 = ix < 0x3f300000, r1 = ix < 0x3f980000, r2 = ix < 0x401c0000;
+    const float A = r0 ? 2.0f : 1.0f;
+    const float B = r1 ? 1.0f : 1.5f; // ranges 0 and 1 subtract 1, range 2 subtracts 1.5
+    const float C = r0 ? 2.0f : 1.0f;
+    const float D = r1 ? 1.0f : 1.5f;
+    float num = r2 ? (A * ax - B) : -1.0f;
+    float den = r2 ? (C + D * ax) : ax;
+    num = small ? x : num;
+    den = small ? 1.0f : den;
+    const float hi = r0 ? 4.6364760399e-01f : r1 ? 7.8539812565e-01f : r2 ? 9.8279368877e-01f : 1.5707962513e+00f;
+    const float lo = r0 ? 5.0121582440e-09f : r1 ? 3.7748947079e-08f : r2 ? 3.4473217170e-08f : 7.5497894159e-08f;
+    const float xr = num / den;
+    const float z = xr * xr;
     const float w = z * z;
     const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
     const float s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
-    if (id < 0) return x - x * (s1 + s2);
-    z = hi - ((x * (s1 + s2) - lo) - x);
-    return (hx < 0) ? -z : z;
+    const float t = xr * (s1 + s2);
+    const float zz = hi - ((t - lo) - xr);
+    float r = small ? (xr - t) : ((hx < 0) ? -zz : zz);
+    r = (ix < 0x31000000) ? x : r; // |x| < 2^-29
+    if (ix >= 0x4c000000) {        // |x| >= 2^25 (or nan)
+        const float big = 1.5707962513e+00f + 7.5497894159e-08f;
+        r = (ix > 0x7f800000) ? x + x : ((hx > 0) ? big : -big);
+    }
+    return r;
 }
 
-// float atan2f(float y, float x) -- FDLIBM e_atan2f.c
-LRM_HD float lrm_atan2f(float y, float x) {
-    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f,
-                pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+// the rare arguments of atan2f: zeros, infinities, nans (FDLIBM e_atan2f.c, verbatim structure)
+LRM_HD float lrm_atan2f_special(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f;
     const int32_t hx = (int32_t)lrm_f2u(x), hy = (int32_t)lrm_f2u(y);
     const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
     if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
-    if (hx == 0x3f800000) return lrm_atanf(y);
     const int32_t m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
     if (iy == 0) {
         if (m < 2) return y;
@@ -104,27 +103,33 @@ LRM_HD float lrm_atan2f(float y, float x) {
             case 2: return 3.0f * pi_o_4 + tiny;
             default: return -3.0f * pi_o_4 - tiny;
             }
-        } else {
-            switch (m) {
-            case 0: return 0.0f;
-            case 1: return -0.0f;
-            case 2: return pi + tiny;
-            default: return -pi - tiny;
-            }
+        }
+        switch (m) {
+        case 0: return 0.0f;
+        case 1: return -0.0f;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
         }
     }
-    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny; // iy == inf
+}
+
+// float atan2f(float y, float x) -- FDLIBM e_atan2f.c.  (Its x == 1 shortcut returns atanf(y), which
+// is what the general path computes for x == 1, so it is not kept as a separate case.)
+LRM_HD float lrm_atan2f(float y, float x) {
+    const float pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)lrm_f2u(x), hy = (int32_t)lrm_f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (__builtin_expect((ix == 0) | (iy == 0) | (ix >= 0x7f800000) | (iy >= 0x7f800000), 0))
+        return lrm_atan2f_special(y, x);
     const int32_t k = (iy - ix) >> 23;
-    float z;
-    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
-    else if (hx < 0 && k < -60) z = 0.0f;
-    else z = lrm_atanf(fabsf(y / x));
-    switch (m) {
-    case 0: return z;
-    case 1: return lrm_u2f(lrm_f2u(z) ^ 0x80000000u);
-    case 2: return pi - (z - pi_lo);
-    default: return (z - pi_lo) - pi;
-    }
+    float z = lrm_atanf(fabsf(y / x));
+    z = (hx < 0 && k < -60) ? 0.0f : z;
+    z = (k > 60) ? pi_o_2 + 0.5f * pi_lo : z;
+    const float zp = z - pi_lo;
+    const float r_neg = (hy < 0) ? (zp - pi) : (pi - zp);          // x < 0
+    const float r_pos = lrm_u2f(lrm_f2u(z) ^ ((uint32_t)hy & 0x80000000u)); // x > 0: z with the sign of y
+    return (hx < 0) ? r_neg : r_pos;
 }
 
 // void sincosf(float, float*, float*) -- ARM optimized routines / glibc s_sincosf.h

@@ -26,23 +26,26 @@ constexpr int kBlock = 256;
 #define LRM_REACH_MIN_WAVES 1
 #endif
 
-// LDS image of the per-lane-indexed tables: 16 circles + their filter records (768 B)
+// LDS image of the per-lane-indexed tables: circle lists, filter records, corner points (~2 KB)
 struct LdsTables {
     LrmCircle lists[16];
-    LrmCompiledLeg::FastCircle flists[16];
     LrmCompiledLeg::LeanCircle lean[16];
+    LrmCompiledLeg::DistCircle dist[16];
+    LrmCircle corners[LRM_N_CORNERS];
 };
 
 __device__ __forceinline__ void stage_lists(const LrmCompiledLeg& L, LdsTables* t) {
     // 2 x 64 floats; one float of each table per thread of the first wave
     const float* src = reinterpret_cast<const float*>(&L.lists[0][0]);
-    const float* fsrc = reinterpret_cast<const float*>(&L.flists[0][0]);
     const float* lsrc = reinterpret_cast<const float*>(&L.lean[0][0]);
+    const float* dsrc = reinterpret_cast<const float*>(&L.dist_tab[0][0]);
+    const float* csrc = reinterpret_cast<const float*>(&L.corner_tab[0]);
     if (threadIdx.x < 64) {
         reinterpret_cast<float*>(t->lists)[threadIdx.x] = src[threadIdx.x];
-        reinterpret_cast<float*>(t->flists)[threadIdx.x] = fsrc[threadIdx.x];
         reinterpret_cast<float*>(t->lean)[threadIdx.x] = lsrc[threadIdx.x];
     }
+    for (int i = threadIdx.x; i < (int)(sizeof(t->dist) / 4); i += kBlock) reinterpret_cast<float*>(t->dist)[i] = dsrc[i];
+    if (threadIdx.x < (int)(sizeof(t->corners) / 4)) reinterpret_cast<float*>(t->corners)[threadIdx.x] = csrc[threadIdx.x];
     __syncthreads();
 }
 
@@ -54,7 +57,7 @@ __device__ __forceinline__ bool eval_reach(const LrmCompiledLeg& L, const LdsTab
 }
 template <bool kFast>
 __device__ __forceinline__ bool eval_dist(const LrmCompiledLeg& L, const LdsTables* t, LrmVec3& p) {
-    if (kFast) return lrm_dist_global_filtered(L, t->lists, t->flists, p);
+    if (kFast) return lrm_dist_global_filtered(L, LrmDistTables{t->lists, t->dist, t->corners}, p);
     return lrm_dist_global(L, t->lists, p);
 }
 template <bool kFast>

@@ -164,99 +164,115 @@ LRM_HD bool lrm_reachable_rotate_leg_fast(const LrmCompiledLeg& L, const LrmComp
 // distance_global: filtered decisions + strict arithmetic for the winner
 // ---------------------------------------------------------------------------------------
 
+// Tables of the lean distance filter as the per-point code sees them (LDS on the device,
+// the LrmCompiledLeg members on the host).
+struct LrmDistTables {
+    const LrmCircle* lists;                        // [16] strict circle lists
+    const LrmCompiledLeg::DistCircle* dist;        // [16]
+    const LrmCircle* corners;                      // [LRM_N_CORNERS]
+};
+
 // eval_plane_circles<DIST> + multi_circle_clamp with filtered decisions.  (x, y) in/out as in
-// lrm_plane_dist.  A decision inside its band sends this ONE call to the strict
-// lrm_plane_dist (same inputs, same outputs); a near-tie between the two nearest boundaries is
-// resolved by evaluating just those two with the strict clamp.  `unc` is only a statistic here.
-LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
-                                const LrmCompiledLeg::FastCircle* flists, float& x, float& y, uint32_t& unc) {
+// lrm_plane_dist.  Every test is a signed distance to its decision boundary (mm): decisions are
+// signs, doubts are the smallest magnitudes against one band (no compare/select chains); the
+// candidates are ranked as integer keys (distance bits with the candidate number in the 4 low
+// bits) through a 3-deep sorting network.  A decision inside its band sends this ONE call to the
+// strict lrm_plane_dist; a near-tie between the two nearest boundaries is resolved by evaluating
+// just those two with the strict clamp.  `unc` is only a statistic here.
+LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, float& x, float& y, uint32_t& unc) {
     const float x_in = x, y_in = y;
     x -= L.coxa_length;
-    uint32_t lu = 0;
-    const float S = fabsf(x) + fabsf(y) + L.fast_scale;
-    const float band = LRM_BAND * S;
-    const float band_q = LRM_BAND * (2.0f * L.fast_scale); // clamp points live on the circles
-    const int reg = lrm_region_fast(L, x, y, band, lu);
-    const LrmCircle* list = lists + reg * LRM_N_CIRCLES;
-    const LrmCompiledLeg::FastCircle* flist = flists + reg * LRM_N_CIRCLES;
-
-    bool overall = true;
-    float best = 3.0e38f, second = 3.0e38f, third = 3.0e38f; // approximate |d|, ascending
-    int win = -1, win2 = -1;                                 // 0..3 circle, 4.. corner, -1 none
+    const float band = LRM_BAND * (fabsf(x) + fabsf(y) + L.fast_scale);
+    // region (circles.cu.h:48-78)
+    const float t_mid = __builtin_fmaf(L.dir_cos[0], y, -(L.dir_sin[0] * x));
+    const float t_s0 = __builtin_fmaf(L.dir_cos[1], y, -(L.dir_sin[1] * x));
+    const float t_s1 = __builtin_fmaf(L.dir_cos[2], y, -(L.dir_sin[2] * x));
+    const bool ypos = !(lrm_f2u(y) >> 31);
+    const bool upper = lrm_gt_from_t(t_mid, ypos, L.region_mid >= 0.f);
+    const bool more0 = lrm_gt_from_t(t_s0, ypos, L.full_sat[0] >= 0.f);
+    const bool more1 = lrm_gt_from_t(t_s1, ypos, L.full_sat[1] >= 0.f);
+    const bool more = (upper & more1) | ((!upper) & more0);
+    const int reg = (upper ? 8 : 0) + ((upper != more) ? 4 : 0);
+    float macc = fminf(fminf(fabsf(t_mid), fabsf(t_s0)), fminf(fabsf(t_s1), fmaxf(x, fabsf(y))));
+    float maccq = 3.0e38f, magmin = 3.0e38f, vacc = -3.0e38f;
+    const LrmCompiledLeg::DistCircle* dt = T.dist + reg;
+    uint32_t key[LRM_N_CIRCLES];
 #pragma unroll
     for (int i = 0; i < LRM_N_CIRCLES; i++) {
-        const LrmCircle c = list[i];
-        const LrmCompiledLeg::FastCircle f = flist[i];
-        float vx, vy, m, ad, qx, qy;
-        {
-#pragma clang fp contract(fast)
-            vx = x - c.x;
-            vy = y - c.y;
-            m = vx * vx + vy * vy;
-            const float q = m - f.T;
-            lu |= !(fabsf(q) > f.g * band) ? 8u : 0u;
-            overall = overall & ((q * f.sg) < 0.f);
-            const float rs = LRM_FAST_RSQ(m);
-            const float mag = m * rs;
-            ad = fabsf(c.r - mag);
-            // the strict clamp replaces the direction by (1,0) when mag < margin (one_leg.cu:54-58)
-            lu |= !(mag > 0.01f) ? 16u : 0u;
-            const float k = c.r * rs;
-            qx = c.x + vx * k;
-            qy = c.y + vy * k;
-        }
-        // validity of the clamp point against the other three circles (its own: |d| ~ 0 < margin)
-        bool ok = true;
+        const LrmCompiledLeg::DistCircle d = dt[i];
+        const float vx = x - d.x, vy = y - d.y;
+        const float m = __builtin_fmaf(vy, vy, vx * vx);
+        const float pv = __builtin_fmaf(m, d.gs, d.c); // validity of the point itself
+        vacc = fmaxf(vacc, pv);
+        macc = fminf(macc, fabsf(pv));
+        const float rs = LRM_FAST_RSQ(m);
+        const float mag = m * rs;
+        magmin = fminf(magmin, mag);
+        const float ad = fabsf(d.r - mag);
+        // validity of the clamp point against the other three circles, in arc form
+        const float w0 = __builtin_fmaf(vx, d.arc[0].ex, vy * d.arc[0].ey) * rs;
+        const float w1 = __builtin_fmaf(vx, d.arc[1].ex, vy * d.arc[1].ey) * rs;
+        const float w2 = __builtin_fmaf(vx, d.arc[2].ex, vy * d.arc[2].ey) * rs;
+        const float q0 = __builtin_fmaf(w0, d.arc[0].P, d.arc[0].Q);
+        const float q1 = __builtin_fmaf(w1, d.arc[1].P, d.arc[1].Q);
+        const float q2 = __builtin_fmaf(w2, d.arc[2].P, d.arc[2].Q);
+        const float okv = fmaxf(fmaxf(q0, q1), q2);
+        maccq = fminf(maccq, fminf(fminf(fabsf(q0), fabsf(q1)), fabsf(q2)));
+        // an invalid clamp ranks as +inf (exponent all ones, mantissa = candidate number only)
+        key[i] = ((okv < 0.f) ? (lrm_f2u(ad) & ~15u) : 0x7f800000u) | (uint32_t)i;
+    }
+    const bool overall = vacc < 0.f;
+    // sorted triple (a <= b <= c) of candidate keys
+    uint32_t a = key[0] < key[1] ? key[0] : key[1];
+    uint32_t b = key[0] < key[1] ? key[1] : key[0];
+    uint32_t c = 0x7f80000fu;
+    auto insert = [&](uint32_t k) {
+        const uint32_t t1 = a > k ? a : k;
+        a = a < k ? a : k;
+        const uint32_t t2 = b > t1 ? b : t1;
+        b = b < t1 ? b : t1;
+        c = c < t2 ? c : t2;
+    };
+    insert(key[2]);
+    insert(key[3]);
+    // corner points only matter when the origin is invalid (one_leg.cu:109-116)
+    const uint32_t corner_keep = overall ? 0u : 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < LRM_N_CIRCLES; j++)
-            if (j != i) ok = ok & lrm_valid_fast(list[j], flist[j], qx, qy, band_q, lu);
-        if (ok) {
-            if (ad < best) { third = second; second = best; win2 = win; best = ad; win = i; }
-            else if (ad < second) { third = second; second = ad; win2 = i; }
-            else if (ad < third) { third = ad; }
+    for (int i = 0; i < LRM_N_CORNERS; i++) {
+        if (i < L.n_ucorners) { // wave-uniform
+            const float vx = x - L.ucorner_x[i], vy = y - L.ucorner_y[i];
+            const float ad = LRM_FAST_SQRT(__builtin_fmaf(vy, vy, vx * vx));
+            insert((((lrm_f2u(ad) & ~15u) & corner_keep) | (0x7f800000u & ~corner_keep)) | (uint32_t)(LRM_N_CIRCLES + i));
         }
     }
-    if (!overall) {
-        for (int i = 0; i < L.n_ucorners; i++) {
-            float ad;
-            {
-#pragma clang fp contract(fast)
-                const float vx = x - L.ucorner_x[i], vy = y - L.ucorner_y[i];
-                ad = LRM_FAST_SQRT(vx * vx + vy * vy);
-            }
-            const int id = LRM_N_CIRCLES + i;
-            if (ad < best) { third = second; second = best; win2 = win; best = ad; win = id; }
-            else if (ad < second) { third = second; second = ad; win2 = id; }
-            else if (ad < third) { third = ad; }
-        }
-    }
-    const float tie = 2.0f * band;
-    lu |= (win < 0) ? 32u : 0u;                      // nothing to clamp on: let the strict code say so
-    lu |= !(third - best > tie) ? 32u : 0u;          // three-way near-tie
+    const float av = lrm_u2f(a & ~15u), bv = lrm_u2f(b & ~15u), cv = lrm_u2f(c & ~15u);
+    // the keys drop 4 mantissa bits (< 2e-6 relative); the tie band grows by that much
+    const float tie = __builtin_fmaf(av, 4.0e-6f, 2.0f * band);
+    uint32_t lu = 0;
+    lu |= !(macc > band) ? 1u : 0u;               // region or point-in-circle decision in doubt
+    lu |= !(maccq > L.band_q) ? 4u : 0u;          // clamp-point validity in doubt
+    lu |= !(magmin > 0.01f) ? 16u : 0u;           // at a circle centre the strict clamp switches direction (one_leg.cu:54-58)
+    lu |= !(cv - av > tie) ? 32u : 0u;            // no candidate at all (inf - inf), or a three-way near-tie
     unc |= lu;
     if (lu) { // strict evaluation of this call (rare: a few 1e-4 of the calls)
         x = x_in;
         y = y_in;
-        return lrm_plane_dist(L, lists, x, y);
+        return lrm_plane_dist(L, T.lists, x, y);
     }
     // strict arithmetic for the winner (and the runner-up when the filter cannot separate them)
-    float bx, by, d1;
+    const uint32_t win = a & 15u, win2 = b & 15u;
+    float bx = x, by = y, d1;
     {
-        float cx, cy, cr;
-        bool attract = true, v;
-        if (win < LRM_N_CIRCLES) { const LrmCircle c = list[win]; cx = c.x; cy = c.y; cr = c.r; attract = c.attract != 0.f; }
-        else { cx = L.ucorner_x[win - LRM_N_CIRCLES]; cy = L.ucorner_y[win - LRM_N_CIRCLES]; cr = 0.f; }
-        bx = x;
-        by = y;
-        lrm_clamp_on(cx, cy, cr, attract, bx, by, d1, v);
+        const LrmCircle w = (win < LRM_N_CIRCLES) ? T.lists[reg + win] : T.corners[win - LRM_N_CIRCLES];
+        bool v;
+        lrm_clamp_on(w.x, w.y, w.r, w.attract != 0.f, bx, by, d1, v);
     }
-    if (!(second - best > tie)) {
+    if (!(bv - av > tie)) {
         unc |= 256u; // statistic: local exact tie-break
-        float cx, cy, cr, b2x = x, b2y = y, d2;
-        bool attract = true, v;
-        if (win2 < LRM_N_CIRCLES) { const LrmCircle c = list[win2]; cx = c.x; cy = c.y; cr = c.r; attract = c.attract != 0.f; }
-        else { cx = L.ucorner_x[win2 - LRM_N_CIRCLES]; cy = L.ucorner_y[win2 - LRM_N_CIRCLES]; cr = 0.f; }
-        lrm_clamp_on(cx, cy, cr, attract, b2x, b2y, d2, v);
+        const LrmCircle w = (win2 < LRM_N_CIRCLES) ? T.lists[reg + win2] : T.corners[win2 - LRM_N_CIRCLES];
+        float b2x = x, b2y = y, d2;
+        bool v;
+        lrm_clamp_on(w.x, w.y, w.r, w.attract != 0.f, b2x, b2y, d2, v);
         // the strict loop keeps the earlier entry unless the later one is strictly closer
         const bool first_is_win = win < win2;
         const float df = first_is_win ? d1 : d2, dl = first_is_win ? d2 : d1;
@@ -272,8 +288,7 @@ LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
 
 // finish_finding_closest<bool> (one_leg.cu:215-278); `angle` is the strict atan2f value, so
 // every comparison on it is the strict comparison.
-LRM_HD bool lrm_finish_closest_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
-                                    const LrmCompiledLeg::FastCircle* flists, LrmVec3& p, float angle,
+LRM_HD bool lrm_finish_closest_fast(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& p, float angle,
                                     uint32_t& unc) {
     const bool mega = (angle > L.mega_hi) || (angle < L.mega_lo);
     float sat;
@@ -287,7 +302,7 @@ LRM_HD bool lrm_finish_closest_fast(const LrmCompiledLeg& L, const LrmCircle* li
     p.x = p.x * c - p.y * s;
     p.y = buffer + p.y * c;
     const LrmVec3 save = p;
-    const bool was_valid = lrm_plane_dist_fast(L, lists, flists, p.x, p.z, unc);
+    const bool was_valid = lrm_plane_dist_fast(L, T, p.x, p.z, unc);
     if (was_valid && !mega) {
         // Is the nearer yaw-limit half-plane closer than the in-plane boundary?  Filter first:
         // |save.x*sin(th) + save.y*cos(th)| against |p|, th = -(limit - sat).
@@ -327,8 +342,7 @@ LRM_HD bool lrm_finish_closest_fast(const LrmCompiledLeg& L, const LrmCircle* li
     return was_valid && !saturated;
 }
 
-LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
-                                  const LrmCompiledLeg::FastCircle* flists, LrmVec3& r, uint32_t& unc) {
+LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& r, uint32_t& unc) {
     LrmVec3 a = r;
     a.x -= L.body;
     float buffer = a.x * L.sin_pitch;
@@ -337,8 +351,8 @@ LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmCircle* list
     LrmVec3 b = a;
     const float ang = lrm_atan2f(a.y, a.x);
     const float ang_flip = (ang > 0) ? ang - LRM_PI_F : ang + LRM_PI_F;
-    const bool res = lrm_finish_closest_fast(L, lists, flists, a, ang, unc);
-    const bool resflip = lrm_finish_closest_fast(L, lists, flists, b, ang_flip, unc);
+    const bool res = lrm_finish_closest_fast(L, T, a, ang, unc);
+    const bool resflip = lrm_finish_closest_fast(L, T, b, ang_flip, unc);
     // The two candidates are often the same configuration up to rounding (yaw within 30 deg of
     // the axis: one of them is "mega-saturated" onto the other): the strict comparison of the
     // strict norms is the only way to pick the same one.
@@ -350,13 +364,12 @@ LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmCircle* list
     return res || resflip;
 }
 
-LRM_HD bool lrm_dist_global_fast(const LrmCompiledLeg& L, const LrmCircle* lists,
-                                 const LrmCompiledLeg::FastCircle* flists, LrmVec3& p, uint32_t& unc) {
+LRM_HD bool lrm_dist_global_fast(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& p, uint32_t& unc) {
     LrmVec3 u = lrm_qrot(L.inv_rot, p);
     float buffer = u.x * L.sin_body;
     u.x = u.x * L.cos_body - u.y * L.sin_body;
     u.y = buffer + u.y * L.cos_body;
-    const bool r = lrm_dist_circles_fast(L, lists, flists, u, unc);
+    const bool r = lrm_dist_circles_fast(L, T, u, unc);
     buffer = u.x * -L.sin_body;
     u.x = u.x * L.cos_body - u.y * -L.sin_body;
     u.y = buffer + u.y * L.cos_body;
@@ -384,8 +397,7 @@ LRM_HD bool lrm_reachable_rotate_leg_filtered(const LrmCompiledLeg& L, const Lrm
     return r;
 }
 
-LRM_HD bool lrm_dist_global_filtered(const LrmCompiledLeg& L, const LrmCircle* lists,
-                                     const LrmCompiledLeg::FastCircle* flists, LrmVec3& p) {
+LRM_HD bool lrm_dist_global_filtered(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& p) {
     uint32_t stat = 0; // the distance filter resolves its own doubts (see lrm_plane_dist_fast)
-    return lrm_dist_global_fast(L, lists, flists, p, stat);
+    return lrm_dist_global_fast(L, T, p, stat);
 }

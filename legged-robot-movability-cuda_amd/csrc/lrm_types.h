@@ -76,4 +76,19 @@ struct LrmCompiledLeg {
         float x, y, gs, c;
     } lean[4][LRM_N_CIRCLES];
     float band_base, band_slope;        // band = band_base + band_slope * (|px| + |py| + |pz|), see lrm_point_fast.h
+    // ---- lean distance filter ----
+    // Per circle i of a list: the point-validity record, r, and for each other circle j the
+    // "arc" record that answers "is the clamp point of i valid for j" without building the clamp
+    // point:  val_ij = P * ((p - c_i) . e_ij / |p - c_i|) + Q  (mm, < 0 = valid), with
+    // e_ij = c_i - c_j, P = 2 r_i gs_j, Q = (|e_ij|^2 + r_i^2 - T_j) gs_j.
+    struct alignas(16) DistCircle {
+        float x, y, gs, c;
+        float r, attract, pad0, pad1;
+        struct alignas(16) Arc {
+            float ex, ey, P, Q;
+        } arc[3];
+    } dist_tab[4][LRM_N_CIRCLES];
+    LrmCircle corner_tab[LRM_N_CORNERS]; // de-duplicated corner points as zero-radius circles
+    float band_q;                        // LRM_BAND * 2 * fast_scale: clamp points live on the circles
+    float pad3_[3];
 };
