@@ -291,6 +291,29 @@ int lrm_dist_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, co
 
 // ---- body x target aggregation ---------------------------------------------------------
 namespace {
+// Library-owned scratch for the tile bounding boxes of lrm_reach_any_dev (6 floats per 1024
+// targets), grown on demand: the first call for a larger cloud allocates (not capturable in a
+// graph); later calls only launch.
+float* g_boxes = nullptr;
+size_t g_boxes_cap = 0; // tiles
+int g_boxes_dev = -1;
+int tile_boxes(size_t nt, float** out) {
+    const size_t ntiles = (nt + 1023) / 1024;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+    if (ntiles > g_boxes_cap || dev != g_boxes_dev) {
+        if (g_boxes && dev == g_boxes_dev) (void)hipFree(g_boxes);
+        void* p = nullptr;
+        const size_t cap = ntiles + ntiles / 2 + 16;
+        HIP_TRY(hipMalloc(&p, cap * 6 * sizeof(float)), "hipMalloc tile boxes");
+        g_boxes = static_cast<float*>(p);
+        g_boxes_cap = cap;
+        g_boxes_dev = dev;
+    }
+    *out = g_boxes;
+    return LRM_OK;
+}
+
 // A small per-process pool of device slots for the compiled legs of in-flight launches, so
 // that the launch path does not allocate.  16 slots x LRM_MAX_LEGS; a slot is reused after
 // 16 further launches, far beyond any stream's queue depth in this library's use.
@@ -330,8 +353,13 @@ int lrm_reach_any_dev(const float* bx, const float* by, const float* bz, size_t 
     // pageable-source async copies are staged by the runtime before returning, so host_legs may die
     bool fast = g_mode == LRM_MODE_FAST;
     for (size_t l = 0; l < nlegs; l++) fast = fast && host_legs[l].fast_ok;
-    HIP_TRY(lrm_launch_reach_any(bx, by, bz, nb, tx, ty, tz, nt, dev_legs, (int)nlegs, out_leg_body, all_legs_out,
-                                 fast, (hipStream_t)stream), "reach_any launch");
+    float* boxes = nullptr;
+    if (nt >= 4096) { // below that the whole cloud is a handful of tiles: nothing to skip
+        rc = tile_boxes(nt, &boxes);
+        if (rc != LRM_OK) return rc;
+    }
+    HIP_TRY(lrm_launch_reach_any(bx, by, bz, nb, tx, ty, tz, nt, dev_legs, (int)nlegs, boxes, out_leg_body,
+                                 all_legs_out, fast, (hipStream_t)stream), "reach_any launch");
     return LRM_OK;
 }
 

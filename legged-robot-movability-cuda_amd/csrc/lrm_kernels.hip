@@ -339,88 +339,190 @@ __global__ __launch_bounds__(kBlock) void dist_aos_kernel(const float* __restric
 __global__ void warmup_kernel() {}
 
 // ------------------------------------------------------------------------------------
-// Body x target aggregation: reach_mem_kernel (several_leg.cu:92-129) for all legs and
-// all targets in ONE launch.
-//   grid  = (ceil(nb / kBodiesPerBlock), nlegs), block = 256 threads = 4 waves
-//   a wave owns kBodiesPerWave bodies; lane = target inside a 64-target slice of the
-//   LDS-staged target tile; __ballot over the wave is the "any" reduction, and a body that
-//   already has a reachable target is never evaluated again (early exit per body, per
-//   wave, per block).
-// Each (body, target) pair first passes a conservative sphere test (|t - b|^2 against the
-// leg's total length, with slack): pairs outside cannot be reachable, so skipping them does
-// not change any output bit.
+// Body x target aggregation: reach_mem_kernel (several_leg.cu:92-129) for all legs and all
+// targets in ONE launch.
+//   block = 4 waves; each wave owns one body at a time and ALL legs of it; the four waves walk
+//   the same 1024-target LDS tile.
+//   Stage 1 (every target): lane = target, conservative sphere test |t - b|^2 <= reach^2 (pairs
+//   outside cannot be reachable: skipping them changes no output), __ballot + mbcnt prefix
+//   append the survivors to the wave's LDS queue.
+//   Stage 2 (full 64-lane batches of survivors): for every leg that has not found a target yet,
+//   lane = queued target -> filtered reachable_rotate_leg -> __ballot is the "any".
+//   A body whose legs have all found a target stops consuming work.
+// The reference launches Nt/512 kernels per leg and re-tests every pair (several_leg.cu:131-157).
 // ------------------------------------------------------------------------------------
 constexpr int kWaves = kBlock / 64;
-constexpr int kBodiesPerWave = 4;
-constexpr int kBodiesPerBlock = kWaves * kBodiesPerWave;
 constexpr int kTargetTile = 1024;
+constexpr int kQueue = 128;
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Axis-aligned bounding box of every 1024-target tile (one block per tile): lets reach_any_kernel
+// skip, per group of four bodies, the tiles no body can reach.  Pays off when the cloud has
+// spatial locality in memory order (terrain rasters, Morton-sorted scans); costs one pass otherwise.
+__global__ __launch_bounds__(kBlock) void tile_aabb_kernel(const float* __restrict__ tx, const float* __restrict__ ty,
+                                                           const float* __restrict__ tz, size_t nt,
+                                                           float* __restrict__ boxes /* [ntiles][6] */) {
+    __shared__ float s_red[6][kBlock / 64];
+    const size_t t0 = (size_t)blockIdx.x * 1024;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (size_t i = t0 + threadIdx.x; i < t0 + 1024 && i < nt; i += kBlock) {
+        const float v[3] = {tx[i], ty[i], tz[i]};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(lo[a], v[a]);
+            hi[a] = fmaxf(hi[a], v[a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 3; a++) {
+            s_red[a][threadIdx.x >> 6] = lo[a];
+            s_red[3 + a][threadIdx.x >> 6] = hi[a];
+        }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s_red[threadIdx.x][0];
+        for (int w = 1; w < kBlock / 64; w++) v = (threadIdx.x < 3) ? fminf(v, s_red[threadIdx.x][w]) : fmaxf(v, s_red[threadIdx.x][w]);
+        boxes[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
 
 template <bool kFast>
 __global__ __launch_bounds__(kBlock) void reach_any_kernel(
     const float* __restrict__ bx, const float* __restrict__ by, const float* __restrict__ bz, size_t nb,
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, size_t nt,
-    const LrmCompiledLeg* __restrict__ legs, uint8_t* __restrict__ out) {
-    __shared__ LdsTables s_tab;
+    const LrmCompiledLeg* __restrict__ legs, int nlegs, const float* __restrict__ boxes,
+    uint8_t* __restrict__ out, uint8_t* __restrict__ all_out) {
     __shared__ float s_tx[kTargetTile], s_ty[kTargetTile], s_tz[kTargetTile];
-    __shared__ int s_todo; // waves of this block that still have an unsatisfied body
+    __shared__ float s_qx[kWaves][kQueue], s_qy[kWaves][kQueue], s_qz[kWaves][kQueue];
+    __shared__ LrmCompiledLeg::LeanCircle s_lean[LRM_MAX_LEGS][16];
+    __shared__ int s_todo;
+    __shared__ unsigned s_near[2];
 
-    const LrmCompiledLeg& L = legs[blockIdx.y];
-    stage_lists(L, &s_tab);
+    for (int i = threadIdx.x; i < nlegs * 64; i += kBlock)
+        reinterpret_cast<float*>(&s_lean[i >> 6][0])[i & 63] = reinterpret_cast<const float*>(&legs[i >> 6].lean[0][0])[i & 63];
+    float r2max = 0.f;
+    for (int l = 0; l < nlegs; l++) r2max = fmaxf(r2max, legs[l].reach_r2_max);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t body0 = (size_t)blockIdx.x * kBodiesPerBlock + (size_t)wave * kBodiesPerWave;
+    const uint32_t all_found = (1u << nlegs) - 1u;
+    float* qx = s_qx[wave];
+    float* qy = s_qy[wave];
+    float* qz = s_qz[wave];
 
-    LrmVec3 body[kBodiesPerWave];
-    bool found[kBodiesPerWave];
-#pragma unroll
-    for (int k = 0; k < kBodiesPerWave; k++) {
-        const size_t b = body0 + k;
+    for (size_t group = blockIdx.x; group * kWaves < nb; group += gridDim.x) {
+        const size_t b = group * kWaves + wave;
         const bool live = b < nb;
-        body[k] = live ? LrmVec3{bx[b], by[b], bz[b]} : LrmVec3{0.f, 0.f, 0.f};
-        found[k] = !live; // out-of-range bodies need no work
-    }
-    const float r2max = L.reach_r2_max;
+        const LrmVec3 body = live ? LrmVec3{bx[b], by[b], bz[b]} : LrmVec3{0.f, 0.f, 0.f};
+        uint32_t found = live ? 0u : all_found; // bit l: leg l has a reachable target
+        int count = 0;                           // survivors waiting in this wave's queue
 
-    for (size_t t0 = 0; t0 < nt; t0 += kTargetTile) {
-        const int tile_n = (int)((nt - t0 < (size_t)kTargetTile) ? (nt - t0) : (size_t)kTargetTile);
-        __syncthreads(); // previous tile fully consumed
-        if (threadIdx.x == 0) s_todo = 0;
-        for (int i = threadIdx.x; i < tile_n; i += kBlock) {
-            s_tx[i] = tx[t0 + i];
-            s_ty[i] = ty[t0 + i];
-            s_tz[i] = tz[t0 + i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kBodiesPerWave; k++) {
-            if (found[k]) continue; // wave-uniform
-            for (int s = 0; s < tile_n; s += 64) {
-                const int i = s + lane;
+        // stage 2: the first `m` queue entries against every leg still searching
+        auto process = [&](int m) {
+            LrmVec3 t{0.f, 0.f, 0.f};
+            if (lane < m) t = LrmVec3{qx[lane], qy[lane], qz[lane]};
+            for (int l = 0; l < nlegs; l++) {
+                if ((found >> l) & 1u) continue; // wave-uniform
                 bool hit = false;
-                if (i < tile_n) {
-                    const LrmVec3 t{s_tx[i], s_ty[i], s_tz[i]};
-                    const float ddx = t.x - body[k].x, ddy = t.y - body[k].y, ddz = t.z - body[k].z;
-                    const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-                    if (d2 <= r2max) hit = eval_pair<kFast>(L, &s_tab, t, body[k]);
+                if (lane < m) {
+                    if (kFast) hit = lrm_reachable_rotate_leg_filtered(legs[l], &legs[l].lists[0][0], s_lean[l], t, body);
+                    else hit = lrm_reachable_rotate_leg(legs[l], &legs[l].lists[0][0], t, body);
                 }
-                if (__ballot(hit) != 0ull) {
-                    found[k] = true;
-                    break;
+                if (__ballot(hit) != 0ull) found |= 1u << l;
+            }
+        };
+
+        const size_t ntiles = (nt + kTargetTile - 1) / kTargetTile;
+        for (size_t tw0 = 0; tw0 < ntiles; tw0 += 64) {
+          // which of the next 64 tiles can any of the four bodies reach?  (lane = tile)
+          unsigned long long near = ~0ull;
+          if (boxes) {
+              __syncthreads();
+              if (threadIdx.x < 2) s_near[threadIdx.x] = 0u;
+              __syncthreads();
+              bool mine = false;
+              const size_t tl = tw0 + lane;
+              if (tl < ntiles && found != all_found) {
+                  const float* bb = boxes + tl * 6;
+                  const float ex = fmaxf(fmaxf(bb[0] - body.x, body.x - bb[3]), 0.f);
+                  const float ey = fmaxf(fmaxf(bb[1] - body.y, body.y - bb[4]), 0.f);
+                  const float ez = fmaxf(fmaxf(bb[2] - body.z, body.z - bb[5]), 0.f);
+                  // box distance is a lower bound of every member's distance; 1e-3 relative slack
+                  // for the rounding of the bound itself
+                  mine = (ex * ex + ey * ey + ez * ez) * 0.999f <= r2max;
+              }
+              const unsigned long long mm = __ballot(mine);
+              if (lane == 0 && mm) {
+                  atomicOr(&s_near[0], (unsigned)mm);
+                  atomicOr(&s_near[1], (unsigned)(mm >> 32));
+              }
+              __syncthreads();
+              near = (unsigned long long)s_near[0] | ((unsigned long long)s_near[1] << 32);
+          }
+          bool all_done = false;
+          for (int tb = 0; tb < 64 && tw0 + tb < ntiles; tb++) {
+            if (!((near >> tb) & 1ull)) continue; // block-uniform
+            const size_t t0 = (tw0 + tb) * kTargetTile;
+            const int tile_n = (int)((nt - t0 < (size_t)kTargetTile) ? (nt - t0) : (size_t)kTargetTile);
+            __syncthreads(); // previous tile fully consumed (and s_todo read)
+            if (threadIdx.x == 0) s_todo = 0;
+            for (int i = threadIdx.x; i < tile_n; i += kBlock) {
+                s_tx[i] = tx[t0 + i];
+                s_ty[i] = ty[t0 + i];
+                s_tz[i] = tz[t0 + i];
+            }
+            __syncthreads();
+            if (found != all_found) { // wave-uniform
+                for (int s = 0; s < tile_n; s += 64) {
+                    const int i = s + lane;
+                    bool keep = false;
+                    LrmVec3 t{0.f, 0.f, 0.f};
+                    if (i < tile_n) {
+                        t = LrmVec3{s_tx[i], s_ty[i], s_tz[i]};
+                        const float ddx = t.x - body.x, ddy = t.y - body.y, ddz = t.z - body.z;
+                        keep = __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx)) <= r2max;
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (m == 0ull) continue;
+                    if (keep) {
+                        const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        qx[pos] = t.x;
+                        qy[pos] = t.y;
+                        qz[pos] = t.z;
+                    }
+                    count += __builtin_popcountll(m);
+                    wave_lds_fence();
+                    if (count >= 64) {
+                        process(64);
+                        count -= 64;
+                        // the (< 64) entries behind the processed batch move to the front
+                        float mx = 0.f, my = 0.f, mz = 0.f;
+                        if (lane < count) { mx = qx[64 + lane]; my = qy[64 + lane]; mz = qz[64 + lane]; }
+                        wave_lds_fence();
+                        if (lane < count) { qx[lane] = mx; qy[lane] = my; qz[lane] = mz; }
+                        wave_lds_fence();
+                        if (found == all_found) break;
+                    }
                 }
             }
+            if (lane == 0 && found != all_found) atomicAdd(&s_todo, 1);
+            __syncthreads();
+            if (s_todo == 0) { all_done = true; break; } // block-uniform: all four bodies are done
+          }
+          if (all_done) break;
         }
-        bool wave_todo = false;
-#pragma unroll
-        for (int k = 0; k < kBodiesPerWave; k++) wave_todo = wave_todo || !found[k];
-        if (lane == 0 && wave_todo) atomicAdd(&s_todo, 1);
-        __syncthreads();
-        if (s_todo == 0) break; // block-uniform: every body of this block is satisfied
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < kBodiesPerWave; k++) {
-            const size_t b = body0 + k;
-            if (b < nb) out[(size_t)blockIdx.y * nb + b] = found[k] ? 1 : 0;
-        }
+        if (count > 0 && found != all_found) process(count);
+        if (live && lane < nlegs) out[(size_t)lane * nb + b] = (found >> lane) & 1u;
+        if (live && lane == 0 && all_out) all_out[b] = (found == all_found) ? 1 : 0;
     }
 }
 
@@ -566,18 +668,19 @@ hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmComp
 
 hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
                                 const float* ty, const float* tz, size_t nt, const LrmCompiledLeg* legs_dev,
-                                int nlegs, uint8_t* out_leg_body, uint8_t* all_legs_out, bool fast, hipStream_t st) {
-    const dim3 grid((unsigned)((nb + kBodiesPerBlock - 1) / kBodiesPerBlock), (unsigned)nlegs);
-    if (fast) hipLaunchKernelGGL(reach_any_kernel<true>, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev, out_leg_body);
-    else hipLaunchKernelGGL(reach_any_kernel<false>, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev, out_leg_body);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (all_legs_out) {
-        hipLaunchKernelGGL(and_legs_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, st, out_leg_body, nb, nlegs,
-                           all_legs_out);
-        e = hipGetLastError();
+                                int nlegs, float* tile_boxes, uint8_t* out_leg_body, uint8_t* all_legs_out, bool fast,
+                                hipStream_t st) {
+    if (tile_boxes && nt) {
+        hipLaunchKernelGGL(tile_aabb_kernel, dim3((unsigned)((nt + 1023) / 1024)), dim3(kBlock), 0, st, tx, ty, tz, nt, tile_boxes);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
     }
-    return e;
+    size_t groups = (nb + kWaves - 1) / kWaves;
+    if (groups > 256 * 16) groups = 256 * 16; // persistent over body groups beyond that
+    const dim3 grid((unsigned)groups);
+    if (fast) hipLaunchKernelGGL(reach_any_kernel<true>, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev, nlegs, tile_boxes, out_leg_body, all_legs_out);
+    else hipLaunchKernelGGL(reach_any_kernel<false>, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev, nlegs, tile_boxes, out_leg_body, all_legs_out);
+    return hipGetLastError();
 }
 
 hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, const float* cz, size_t nc,

@@ -16,7 +16,8 @@ hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmComp
                                float* dxyz, bool fast, hipStream_t st);
 hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
                                 const float* ty, const float* tz, size_t nt, const LrmCompiledLeg* legs_dev,
-                                int nlegs, uint8_t* out_leg_body, uint8_t* all_legs_out, bool fast, hipStream_t st);
+                                int nlegs, float* tile_boxes /* ntiles x 6 floats of workspace, or null */,
+                                uint8_t* out_leg_body, uint8_t* all_legs_out, bool fast, hipStream_t st);
 hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, const float* cz, size_t nc,
                                    const float* tx, const float* ty, const float* tz, size_t nt, float radius,
                                    float plus_z, float minus_z, uint8_t* out, hipStream_t st);

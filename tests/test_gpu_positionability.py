@@ -169,3 +169,20 @@ def test_robot_full_struct_pipeline_with_reference_culls(lrm, oracle, torch_cuda
     assert np.array_equal(got, want)
     assert 0 < want.sum() < len(want)
     assert (got <= plain).all() and (got != plain).any()  # the culls only remove bodies, and do remove some
+
+
+def test_reach_any_on_terrain_raster_with_tile_culling(lrm, oracle, torch_cuda):
+    """Config-3 shaped input (terrain raster in memory order + lattice bodies): the tile
+    bounding-box cull and the survivor queue must not change any answer."""
+    from lrm_amd import workloads
+    ground = workloads.terrain(160)                      # 25 600 points = 25 tiles
+    bodies = workloads.body_lattice(ground, 700, seed=3)
+    legs = workloads.hexapod(lrm.get_M2_leg, 6)
+    bx, by, bz = soa(torch_cuda, bodies)
+    tx, ty, tz = soa(torch_cuda, ground)
+    out, all_legs = lrm.device.reach_any(bx, by, bz, tx, ty, tz, legs)
+    torch_cuda.cuda.synchronize()
+    want = oracle.reach_any(bodies, ground, legs)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal(all_legs.cpu().numpy(), want.min(axis=0))
+    assert 0.05 < want.mean() < 0.95
