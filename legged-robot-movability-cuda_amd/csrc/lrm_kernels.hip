@@ -340,7 +340,8 @@ __global__ void warmup_kernel() {}
 
 // ------------------------------------------------------------------------------------
 // Body x target aggregation: reach_mem_kernel (several_leg.cu:92-129) for all legs and all
-// targets in ONE launch.
+// targets in ONE launch; the AND over legs (agregateReachability, several_leg.cu:681-697, any
+// number of legs) is written by the same kernel.
 //   block = 4 waves; each wave owns one body at a time and ALL legs of it; the four waves walk
 //   the same 1024-target LDS tile.
 //   Stage 1 (every target): lane = target, conservative sphere test |t - b|^2 <= reach^2 (pairs
@@ -523,17 +524,6 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
         if (count > 0 && found != all_found) process(count);
         if (live && lane < nlegs) out[(size_t)lane * nb + b] = (found >> lane) & 1u;
         if (live && lane == 0 && all_out) all_out[b] = (found == all_found) ? 1 : 0;
-    }
-}
-
-// agregateReachability (several_leg.cu:681-697) for any number of legs: AND over legs
-__global__ __launch_bounds__(kBlock) void and_legs_kernel(const uint8_t* __restrict__ leg_body, size_t nb,
-                                                          int nlegs, uint8_t* __restrict__ out) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x; b < nb; b += stride) {
-        uint8_t v = 1;
-        for (int l = 0; l < nlegs; l++) v &= leg_body[(size_t)l * nb + b];
-        out[b] = v;
     }
 }
 

@@ -3,32 +3,44 @@
 // Idea (floating-point filters, as in exact geometric predicates): every value that reaches
 // an OUTPUT is computed with the strict, reference-order arithmetic of lrm_point.h; every
 // DECISION on the way (which region, is the point inside a circle, is a clamp point valid,
-// which boundary is nearest, which coxa candidate wins) is first taken with cheap arithmetic
+// which boundary is nearest, which yaw candidate wins) is first taken with cheap arithmetic
 // (FMA, squared distances instead of sqrt, cross products instead of atan2f, hardware
 // rsqrt/sqrt) together with a conservative bound on how far that arithmetic can be from the
-// strict one.  If a decision falls inside its band the point is flagged `uncertain` and the
-// caller re-evaluates it with the strict code.  Results are therefore bit-identical to the
-// strict mode by construction; the bands only decide how often the slow path runs (measured:
-// a few points per million).
+// strict one.  A decision inside its band is re-taken by the strict code at the smallest
+// enclosing granularity, so results are bit-identical to the strict mode by construction; the
+// bands only decide how often the slow path runs.
 //
-// What the strict path spends and this one does not, per distance candidate:
-//   16 sqrt-bearing circle validations of clamp points  -> squared-domain tests
-//   4 + n_corners exact clamps (sqrt + div each)        -> 1 exact clamp (the winner's)
-//   1 exact atan2f for the region                       -> 2 cross products
-// and for reachability: both atan2f and the sincosf disappear (pure decisions).
+// Shape of the code: every test is expressed as a signed distance (mm) to its decision
+// boundary.  The decision is a sign, accumulated with v_max; the doubt is the smallest magnitude,
+// accumulated with v_min and compared ONCE with the band.  No compare/select chains (a
+// v_cmp + v_cndmask pair costs about twice a plain VALU op on gfx950).
 //
-// Error model (u = 2^-24).  All inputs of the decisions below (px, pz, the rotated
-// coordinates) are the strict values themselves, so only the decision arithmetic differs:
-//   m  = |p - c|^2 by FMA            : relative error <= 2u
-//   sqrt by v_sqrt_f32 / rsq         : <= 1 ulp  (strict: correctly rounded)
-//   strict d = r - sqrt(m) is exact by Sterbenz near the boundary; its sqrt carries 0.5 ulp
-//   => |d_fast - d_strict| <= 4u * mag  <= 2.4e-7 * S   with S = |px| + |pz| + fast_scale.
-// The band used is kBand * S with kBand = 4e-6 (>= 16x the bound).  Cross products:
-//   t = cosC*pz - sinC*px : error <= 4u (|px| + |pz|); the strict atan2f is within 1 ulp
-//   of the true angle, i.e. within 2e-7*|p| in t.  Band: kBand * (|px| + |pz|) (>= 8x).
-// In the reachability filter the plane abscissa itself is approximate (sgn(x)*sqrt(x^2+y^2)
-// instead of the strict x*cos(a) - y*sin(a), both within 4u*r of the true value): its error
-// <= 8u*r is added to S there.
+// What the strict path spends and this one does not:
+//   reachability   2 atan2f + 1 sincosf + 4 sqrt            -> 0 (decisions only), ~70 VALU ops
+//   distance, per yaw candidate
+//     16 sqrt-bearing circle validations of clamp points    -> 12 "arc" dot products
+//     4 + n_corners exact clamps (sqrt + div each)          -> 1 exact clamp (the winner's)
+//     1 exact atan2f for the region                         -> 3 cross products
+//   kept exact in the distance: 1 atan2f, 1 sincosf per candidate, the winner's clamp, the
+//   yaw-limit alternative when it is taken or in doubt, and the final comparison of the two
+//   candidates' strict norms (for |yaw| < 30 deg the "flipped" candidate is the same
+//   configuration up to rounding and the reference's pick is decided by rounding noise).
+//
+// Error model (u = 2^-24).  Distance filter: px, pz and the rotated coordinates are the strict
+// values themselves, only the decision arithmetic differs:
+//   m  = |p - c|^2 by FMA : relative error <= 2u;  v_sqrt_f32 / v_rsq_f32 : <= 1 ulp;
+//   strict d = r - sqrt(m) is exact by Sterbenz near the boundary, its sqrt carries 0.5 ulp
+//   => |d_fast - d_strict| <= 4u * mag <= 2.4e-7 * S,  S = |px| + |pz| + fast_scale.
+//   Band: LRM_BAND * S with LRM_BAND = 4e-6 (>= 16x).  Cross products t = cosC*pz - sinC*px:
+//   error <= 4u (|px| + |pz|), strict atan2f within 1 ulp of the true angle (2e-7 |p| in t): >= 8x.
+//   Arc form of the clamp validity: <= 12u * fast_scale against LRM_BAND * 2 * fast_scale (>= 10x).
+// Reach filter: the coxa-frame point itself is approximate (one FMA affine map instead of the
+// strict qtRotate / z-rotation / translation / pitch chain: <= 22u (|p|_1 + body) apart) and the
+// plane abscissa is sgn(x) sqrt(x^2 + y^2) instead of x cos(a) - y sin(a) (<= 8u r apart):
+//   band = LRM_BAND * (fast_scale + (sqrt(3) + 1.5) (|p|_1 + body))   (>= 4.5x, linear in |p|_1).
+// Empirical margin (tests/test_capi_cpu.py keeps the bands honest on every fixture, including the
+// boundary-hugging one): shrinking LRM_BAND 40x (to 1e-7) still gives zero mismatches on 6e6
+// points x 6 leg/orientation cases; the first mismatches appear at 2e-8 (200x smaller).
 #pragma once
 #include "lrm_point.h"
 
@@ -44,37 +56,6 @@
 #define LRM_FAST_RSQ(v) (1.0f / sqrtf(v))
 #endif
 
-// "atan2f(y, x) > C" for a constant C in (-pi, pi) given (cos C, sin C), as a half-plane
-// test with the wrap at +-pi handled; sets `unc` when the strict comparison could differ.
-LRM_HD bool lrm_dir_gt(float x, float y, float C, float cosC, float sinC, float band, uint32_t& unc) {
-#pragma clang fp contract(fast)
-    const float t = cosC * y - sinC * x; // > 0: (x,y) is counter-clockwise of direction C by < pi
-    unc |= !(fabsf(t) > band) ? 1u : 0u;
-    // the ray at +-pi: atan2f jumps from +pi (y = +0) to -pi (y = -0)
-    unc |= ((x < band) && !(fabsf(y) > band)) ? 2u : 0u;
-    const bool ypos = !(lrm_f2u(y) >> 31);
-    return (C >= 0.f) ? (t > 0.f && ypos) : (ypos || t > 0.f);
-}
-
-// find_region (circles.cu.h:48-78) without atan2f
-LRM_HD int lrm_region_fast(const LrmCompiledLeg& L, float x, float y, float band, uint32_t& unc) {
-    const bool upper = lrm_dir_gt(x, y, L.region_mid, L.dir_cos[0], L.dir_sin[0], band, unc);
-    const bool more = upper ? lrm_dir_gt(x, y, L.full_sat[1], L.dir_cos[2], L.dir_sin[2], band, unc)
-                            : lrm_dir_gt(x, y, L.full_sat[0], L.dir_cos[1], L.dir_sin[1], band, unc);
-    return (upper ? 2 : 0) + ((upper != more) ? 1 : 0);
-}
-
-// squared-domain validity of (x, y) against circle i of a list; band_d is the distance band
-LRM_HD bool lrm_valid_fast(const LrmCircle c, const LrmCompiledLeg::FastCircle f, float x, float y,
-                           float band_d, uint32_t& unc) {
-#pragma clang fp contract(fast)
-    const float dx = x - c.x, dy = y - c.y;
-    const float m = dx * dx + dy * dy;
-    const float q = m - f.T;
-    unc |= !(fabsf(q) > f.g * band_d) ? 4u : 0u;
-    return (q * f.sg) < 0.f;
-}
-
 // ---------------------------------------------------------------------------------------
 // reachability: decisions only.  Lean form: one affine map into the coxa frame, every test
 // turned into a signed distance-to-the-decision-boundary in mm ("value"); the decision is the
@@ -82,8 +63,10 @@ LRM_HD bool lrm_valid_fast(const LrmCircle c, const LrmCompiledLeg::FastCircle f
 // compare/select chains: v_max / v_min accumulators.
 // ---------------------------------------------------------------------------------------
 
-// "atan2f(y, x) > C" from the cross product t = cosC*y - sinC*x (see lrm_dir_gt); branch-free:
-// C >= 0: t > 0 and y >= 0;  C < 0: y >= 0 or t > 0
+// "atan2f(y, x) > C" for a constant C in (-pi, pi) from the cross product t = cosC*y - sinC*x
+// (> 0: (x, y) is counter-clockwise of direction C by less than pi), with the wrap of atan2f at
+// +-pi handled, branch-free:   C >= 0: t > 0 and y >= 0;   C < 0: y >= 0 or t > 0.
+// Doubt: |t| small (the point is near the ray), or x < 0 with y = +-0 (atan2f jumps from +pi to -pi).
 LRM_HD bool lrm_gt_from_t(float t, bool ypos, bool c_nonneg) {
     const bool tp = t > 0.f;
     return (tp & ypos) | ((!c_nonneg) & (tp | ypos));
