@@ -111,11 +111,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     dist = None
+    # LRM_BENCH_BACKEND=gloo rehearses the multi-rank control flow where RCCL cannot run (several
+    # ranks on one GPU): the bit words then travel through host memory
+    backend = os.environ.get("LRM_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if args.mode:
@@ -131,7 +139,8 @@ def main():
     mask = torch.empty(n, dtype=torch.uint8, device="cuda")
     field = torch.empty((3, n), dtype=torch.float32, device="cuda")
     bits = [torch.empty(nwords, dtype=torch.int64, device="cuda") for _ in range(2)]
-    gathered = [torch.empty(nwords * world, dtype=torch.int64, device="cuda") for _ in range(2)] if world > 1 else None
+    gdev = "cuda" if backend == "nccl" else "cpu"
+    gathered = [torch.empty(nwords * world, dtype=torch.int64, device=gdev) for _ in range(2)] if world > 1 else None
     comm_stream = torch.cuda.Stream() if world > 1 else None
     gather_done = [None, None]
 
@@ -149,7 +158,10 @@ def main():
             ready.record()
             comm_stream.wait_event(ready)
             with torch.cuda.stream(comm_stream):
-                dist.all_gather_into_tensor(gathered[b], bits[b])
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(gathered[b], bits[b])
+                else:  # rehearsal path: through host memory (synchronous)
+                    dist.all_gather_into_tensor(gathered[b], bits[b].cpu())
                 gather_done[b] = torch.cuda.Event()
                 gather_done[b].record()
 
@@ -158,6 +170,11 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def reduce_max(v):
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for k in range(args.warmup):
         step(k)
@@ -169,9 +186,7 @@ def main():
     full_sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = reduce_max(elapsed)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     # secondary figures (not part of the timed region): reach-only and distance-only kernels
@@ -222,8 +237,8 @@ def main():
                 "workload": f"BASELINE config 2: single M2 leg, reach+distance on {n} uniform-random 3-D targets "
                             f"per GPU (seed 42+rank), identity orientation, SoA resident in HBM",
                 "points_per_gpu": n, "mode": mode,
-                "exchange": "none" if world == 1 else "RCCL all-gather of the bit-packed reach mask per step, "
-                                                         "overlapped on a side stream",
+                "exchange": "none" if world == 1 else f"{'RCCL' if backend == 'nccl' else backend} all-gather of the "
+                                                         "bit-packed reach mask per step, overlapped on a side stream",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
