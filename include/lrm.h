@@ -171,6 +171,37 @@ int lrm_any_in_cylinder_dev(const float* cx, const float* cy, const float* cz, s
                             const float* tx, const float* ty, const float* tz, size_t nt,
                             float radius, float plus_z, float minus_z, uint8_t* out, void* stream);
 
+/* ---- octree-culled positionability: apply_oct, several_leg_octree.cu:391-488 ----------------
+ * Breadth-first refinement of the body-position box: per level every child box is tested against
+ * every foothold (and the orientation samples for small boxes) with distance_global for each
+ * mounted leg (validity_child, several_leg_octree.cu:19-151); valid leaves' centres are returned
+ * in depth-first child order (extractValidAsArray, octree_util.cu:128-180).  The compile-time knobs
+ * of settings.h:15-46 are a struct here; lrm_octree_default_settings() fills in the committed
+ * values (root box +-5000 mm, MINBOXSIZE 100, 3x3x3 orientation samples, 4 legs mounted every
+ * pi/4, LegNumberForStab 4, MAX_DEPTH 1).  Level-synchronous flat arrays replace the reference's
+ * device-side cudaMalloc and kernel-launching kernels. */
+typedef struct LrmOctreeSettings {
+    float box_center[3];        /* settings.h:24 BoxCenter        */
+    float box_size[3];          /* settings.h:26 BoxSize (half)   */
+    float min_box;              /* settings.h:17 MINBOXSIZE       */
+    float enable_rot_below;     /* settings.h:33 EnableRotBelow   */
+    float convex_radius;        /* settings.h:34 convexRadius     */
+    int32_t angle_sample[3];    /* settings.h:35 AngleSample      */
+    float angle_minmax[6];      /* settings.h:38 AngleMinMax      */
+    int32_t leg_count;          /* settings.h:41 LegCount         */
+    float leg_mount[8];         /* settings.h:42 LegMount         */
+    int32_t leg_number_for_stab;/* settings.h:46 LegNumberForStab */
+    int32_t max_depth;          /* settings.h:15 MAX_DEPTH        */
+} LrmOctreeSettings;
+void lrm_octree_default_settings(LrmOctreeSettings* out);
+/* footholds: AoS float3 (Array<float3> input of apply_oct); centers_out: room for `capacity` float3;
+ * *n_out = number of valid leaves (if > capacity the call fails with LRM_EINVAL and *n_out tells the
+ * size to retry with); settings = NULL -> defaults; *ms = kernel time. */
+int lrm_apply_oct(const float* footholds_aos, size_t n, const LrmLegDimensions* dim,
+                  const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out,
+                  float* ms);
+const char* lrm_octree_last_error(void);
+
 /* ---- diagnostics -------------------------------------------------------------------------
  * The glibc-exact atan2f / sincosf of the strict kernels (csrc/lrm_exact_math.h) applied to
  * arrays: at2[i] = atan2f(a[i], b[i]); (sn[i], cs[i]) = sincosf(a[i]).  Host build and device

@@ -101,6 +101,29 @@ inline double apply_dist_cpu(const Array<float3> input, const LegDimensions dim,
     return ms;
 }
 
+// apply_oct, several_leg_octree.cu.h:4 / several_leg_octree.cu:391-488: replaces output.elements by a
+// new[]-ed array of the valid leaves' centres (the reference delete[]s the old one, :469-472).
+inline float apply_oct(Array<float3> input, LegDimensions dim, Array<float3>& output) {
+    size_t n = 0, cap = 4096;
+    float ms = 0.f;
+    float3* buf = new float3[cap];
+    int rc = lrm_apply_oct(&input.elements->x, input.length, &dim, nullptr, &buf->x, cap, &n, &ms);
+    if (rc == LRM_EINVAL && n > cap) {
+        delete[] buf;
+        cap = n;
+        buf = new float3[cap];
+        rc = lrm_apply_oct(&input.elements->x, input.length, &dim, nullptr, &buf->x, cap, &n, &ms);
+    }
+    if (rc != LRM_OK) {
+        std::fprintf(stderr, "HIP error in Kernel launch: %s\n", lrm_octree_last_error());
+        std::exit(EXIT_FAILURE);
+    }
+    delete[] output.elements;
+    output.elements = buf;
+    output.length = n;
+    return ms;
+}
+
 inline LegDimensions get_M2_leg(float body_angle) {
     LegDimensions l;
     lrm_get_M2_leg(body_angle, &l);

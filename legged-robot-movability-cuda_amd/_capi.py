@@ -90,6 +90,11 @@ def load():
     for name in ("lrm_get_M2_leg", "lrm_get_moonbot_leg"):
         getattr(L, name).argtypes = [fp, vp]
         getattr(L, name).restype = None
+    L.lrm_octree_default_settings.argtypes = [vp]
+    L.lrm_octree_default_settings.restype = None
+    L.lrm_apply_oct.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp]
+    L.lrm_apply_oct.restype = C.c_int
+    L.lrm_octree_last_error.restype = C.c_char_p
     L.lrm_rotate_leg_data.argtypes = [vp, vp, vp]
     L.lrm_rotate_leg_data.restype = None
     _lib = L
@@ -208,6 +213,39 @@ def apply_dist_cpu(xyz, leg, quat=None):
     check(load().lrm_dist_cpu(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(d), _ptr(v),
                               C.addressof(ms)))
     return d, v, ms.value
+
+
+class OctreeSettings(C.Structure):
+    """LrmOctreeSettings (include/lrm.h): the octree knobs of settings.h:15-46."""
+    _fields_ = [("box_center", C.c_float * 3), ("box_size", C.c_float * 3), ("min_box", C.c_float),
+                ("enable_rot_below", C.c_float), ("convex_radius", C.c_float), ("angle_sample", C.c_int32 * 3),
+                ("angle_minmax", C.c_float * 6), ("leg_count", C.c_int32), ("leg_mount", C.c_float * 8),
+                ("leg_number_for_stab", C.c_int32), ("max_depth", C.c_int32)]
+
+
+def octree_default_settings():
+    s = OctreeSettings()
+    load().lrm_octree_default_settings(C.addressof(s))
+    return s
+
+
+def apply_oct(footholds, leg, settings=None, capacity=None):
+    """apply_oct (several_leg_octree.cu:391-488) -> (centres float32[k,3], kernel ms); GPU."""
+    footholds = _f32(footholds, (-1, 3))
+    cap = capacity if capacity is not None else 4096
+    while True:
+        out = np.zeros((max(cap, 1), 3), np.float32)
+        n_out = C.c_size_t(0)
+        ms = C.c_float(0)
+        rc = load().lrm_apply_oct(_ptr(footholds), len(footholds), _ptr(_f32(leg, (14,))),
+                                  None if settings is None else C.addressof(settings), _ptr(out), cap,
+                                  C.addressof(n_out), C.addressof(ms))
+        if rc == -1 and n_out.value > cap and capacity is None:
+            cap = n_out.value
+            continue
+        if rc != 0:
+            raise LrmError(f"liblrm error {rc}: {load().lrm_octree_last_error().decode()}")
+        return out[: n_out.value].copy(), ms.value
 
 
 def dbg_fast_host(xyz, leg, quat=None):

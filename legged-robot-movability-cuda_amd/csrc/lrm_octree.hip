@@ -1,0 +1,389 @@
+// lrm_octree.hip -- octree-culled positionability (BASELINE config 5), the MI355X re-design of
+// apply_oct / branchKernel / validity_child (several_leg_octree.cu:19-488, octree_util.cu.h).
+//
+// The reference grows the tree from INSIDE kernels: device-side cudaMalloc of the children
+// (several_leg_octree.cu:276), kernels launching kernels (:306, :372), one host iteration per level
+// (:447-452).  HIP has neither device malloc nor dynamic parallelism, and neither is wanted: here
+// the tree is LEVEL-SYNCHRONOUS with flat arrays.  Per level the host creates the children of every
+// node that must be refined (CreateChildBox, octree_util.cu.h:105-151), ONE kernel evaluates all
+// (child, foothold, orientation) work items of the level, and three flag bits per child come back.
+//
+// Work item semantics (validity_child, several_leg_octree.cu:19-151), body = child box centre:
+//   skip   if the foothold is outside the parent-sized box grown by the leg's total length (:76-82)
+//   for each leg mounted at LegMount[l] (settings.h:42): distance_global(foothold - body) -> reachable?,
+//          and does the distance vector fall inside the child box (sphere for small boxes)? (:91-114)
+//   edge   = more than LegCount - LegNumberForStab legs have their boundary inside the box
+//   reach  = parent already valid, or at least LegNumberForStab legs reach the foothold
+//   flags  |= {reach, reach and not edge ("valid leaf"), edge}
+// The reference ORs these flags through racy __shared__ bools per 256-thread block and derives
+// node.onEdge per block (:134-150), which makes its result depend on the launch geometry; here the
+// three ORs are global per child and  onEdge = edge_any and not leaf_any  -- the evident intent.
+// (The call site of apply_oct is dead code in the reference, several_leg.cpp:224; MAX_DEPTH is 1 as
+// committed.  No reference run exists for this path: parity is pinned by composition of the pinned
+// distance_global only, against tests/octree_oracle.py.)
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/lrm.h"
+#include "lrm_compile.h"
+#include "lrm_point.h"
+#include "lrm_point_fast.h"
+
+namespace {
+
+constexpr int kOctBlock = 256;
+
+struct OctChild {          // one child box of the level being evaluated
+    float c[3], h[3];      // centre, half size ("topOffset")
+    float ph[3];           // parent half size
+    float margin;          // 0 when rotations are active, EnableRotBelow / 3 otherwise
+    int32_t n_angles;      // 27 when parent.half.x < EnableRotBelow, else 1
+    int32_t parent_valid;
+    int32_t skip;          // dead quadrant or already valid
+    int32_t pad;
+};
+
+// isInBox, octree_util.cu.h:153-159 (note the asymmetric comparisons)
+__device__ __forceinline__ bool in_box(LrmVec3 v, float hx, float hy, float hz) {
+    hx = fabsf(hx); hy = fabsf(hy); hz = fabsf(hz);
+    return hx >= v.x && hy >= v.y && hz >= v.z && -hx < v.x && -hy < v.y && -hz < v.z;
+}
+
+template <bool kFast>
+__global__ __launch_bounds__(kOctBlock) void oct_validity_kernel(
+    const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
+    const float* __restrict__ fy, const float* __restrict__ fz, size_t nf,
+    const LrmCompiledLeg* __restrict__ legs /* [n_angles_max][leg_count] */, int leg_count, int legs_for_stab,
+    float reach_len, float convex_r2, uint32_t* __restrict__ flags /* per child: 1 reach, 2 valid leaf, 4 edge */) {
+    const OctChild ch = children[blockIdx.y];
+    if (ch.skip) return;
+    const float h2 = ch.h[0] * ch.h[0] + ch.h[1] * ch.h[1] + ch.h[2] * ch.h[2]; // linormRaw(topOffset)
+    uint32_t mine = 0;
+    const size_t stride = (size_t)gridDim.x * kOctBlock;
+    for (size_t f = (size_t)blockIdx.x * kOctBlock + threadIdx.x; f < nf; f += stride) {
+        const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
+        // elongated parent box, several_leg_octree.cu:76-82
+        if (!in_box(vect, ch.ph[0] + reach_len, ch.ph[1] + reach_len, ch.ph[2] + reach_len)) continue;
+        for (int a = 0; a < ch.n_angles; a++) {
+            int reach_count = 0, cross_count = 0;
+            for (int l = 0; l < leg_count; l++) {
+                const LrmCompiledLeg& L = legs[a * leg_count + l];
+                LrmVec3 v = vect;
+                bool sub;
+                if (kFast) sub = lrm_dist_global_filtered(L, LrmDistTables{&L.lists[0][0], &L.dist_tab[0][0], &L.corner_tab[0]}, v);
+                else sub = lrm_dist_global(L, &L.lists[0][0], v);
+                bool cross;
+                if (h2 > convex_r2) cross = in_box(v, ch.h[0], ch.h[1], ch.h[2]);   // :103-107 (margin unused there)
+                else cross = (v.x * v.x + v.y * v.y + v.z * v.z) < h2 + ch.margin;  // :108-109
+                cross_count += cross;
+                reach_count += sub;
+            }
+            const bool edge = cross_count > leg_count - legs_for_stab;
+            const bool reach = ch.parent_valid || (reach_count >= legs_for_stab);
+            mine |= (reach ? 1u : 0u) | ((reach && !edge) ? 2u : 0u) | (edge ? 4u : 0u);
+        }
+    }
+    // wave OR, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) mine |= __shfl_xor(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicOr(&flags[blockIdx.y], mine);
+}
+
+// ---- host side ------------------------------------------------------------------------------
+struct Quat {
+    float x, y, z, w;
+};
+Quat q_mul(Quat a, Quat b) { // qtMultiply, unified_math_cuda.cu.h:40-46
+    Quat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    return r;
+}
+Quat q_axis(float ax, float ay, float az, float angle) { // quatFromVectAngle, :48-57
+    float s, c;
+    sincosf(angle / 2, &s, &c);
+    const float mag = sqrtf(ax * ax + ay * ay + az * az);
+    return Quat{s, c * ax / mag, c * ay / mag, c * az / mag};
+}
+// QuaternionFromAngleIndex + RPYtoQuat, octree_util.cu.h:164-198
+Quat quat_from_angle_index(unsigned idx, const LrmOctreeSettings& st) {
+    float rpy[3];
+    unsigned red = idx;
+    for (int i = 0; i < 3; i++) {
+        const unsigned char max_ind = (unsigned char)st.angle_sample[i];
+        unsigned char ind = (unsigned char)(red % max_ind);
+        ind = (unsigned char)((ind + (ind / 2)) % max_ind); // the reference's "starts at middle" ordering
+        red = red / max_ind;
+        const int den = (max_ind - 1) > 1 ? (max_ind - 1) : 1;
+        const float x = (float)ind / (unsigned char)den;
+        rpy[i] = (1 - x) * st.angle_minmax[i * 2] + x * st.angle_minmax[i * 2 + 1];
+    }
+    Quat q = q_mul(q_axis(0, 1, 0, rpy[1]), q_axis(1, 0, 0, rpy[0]));
+    return q_mul(q_axis(0, 0, 1, rpy[2]), q);
+}
+
+struct Node {
+    float c[3], h[3];
+    bool validity = false, leaf = false, raw = false, on_edge = false, dead = false;
+    int first_child = -1; // index of 8 consecutive children, -1 if none
+};
+
+// CreateChildBox (octree_util.cu.h:105-151) for SUB_QUAD = 1, quadCount = 3, no "small" dimension.
+// Returns false for a dead quadrant.  *missing = number of dimensions too small to split.
+bool create_child_box(const Node& parent, unsigned index, float min_box, Node* child, int* missing) {
+    // the 3-bit child index, bit-reversed: bit 0 of `quadr` is bit 2 of the index, etc.
+    unsigned quadr = ((index & 1u) << 2) | (index & 2u) | ((index >> 2) & 1u);
+    std::memcpy(child->c, parent.c, sizeof child->c);
+    std::memcpy(child->h, parent.h, sizeof child->h);
+    float div[3] = {2, 2, 2};
+    unsigned upper = 2;
+    *missing = 0;
+    for (unsigned q = 0; q < 3; q++) {
+        if (child->h[q] < min_box) {
+            (*missing)++;
+            if ((quadr >> upper) & 1u) return false; // DEADQUADRAN: this half does not exist
+            // bitShiftBetween(quadr, q, 3, 1): bits q..3 move up by one (bit 3 drops out)
+            const unsigned mask = ((1u << 4) - 1u) ^ ((1u << q) - 1u);
+            quadr = (quadr & ~mask) | (((quadr & mask) << 1) & mask);
+            div[q] = 1;
+        }
+    }
+    for (int q = 0; q < 3; q++) {
+        const float old = child->h[q];
+        child->h[q] = old / div[q];
+        const float move = old - child->h[q];
+        child->c[q] = child->c[q] + (((quadr >> q) & 1u) ? move * -1 : move); // flipVectorOnQuad
+    }
+    return true;
+}
+
+thread_local std::string g_oct_err;
+
+} // namespace
+
+extern "C" {
+
+void lrm_octree_default_settings(LrmOctreeSettings* s) {
+    const float pi = 3.14159265358979323846264338327950288419716939937510582097f;
+    std::memset(s, 0, sizeof *s);
+    for (int i = 0; i < 3; i++) {
+        s->box_center[i] = 0.f;   // settings.h:24
+        s->box_size[i] = 5000.f;  // settings.h:26
+        s->angle_sample[i] = 3;   // settings.h:35
+    }
+    s->min_box = 100.f;           // settings.h:17
+    s->enable_rot_below = 50.f;   // settings.h:33
+    s->convex_radius = 100.f;     // settings.h:34
+    const float mm[6] = {-pi / 4, pi / 4, -pi / 8, pi / 8, -pi / 8, pi / 8}; // settings.h:38
+    std::memcpy(s->angle_minmax, mm, sizeof mm);
+    s->leg_count = 4;             // settings.h:41
+    for (int l = 0; l < 4; l++) s->leg_mount[l] = pi / 4 * l; // settings.h:42
+    s->leg_number_for_stab = 4;   // settings.h:46
+    s->max_depth = 1;             // settings.h:15 MAX_DEPTH
+}
+
+const char* lrm_octree_last_error(void) { return g_oct_err.c_str(); }
+
+// apply_oct, several_leg_octree.cu:391-488
+int lrm_apply_oct(const float* footholds, size_t nf, const LrmLegDimensions* dim, const LrmOctreeSettings* st_in,
+                  float* centers_out, size_t capacity, size_t* n_out, float* ms) {
+    auto fail = [](int code, const char* w) { g_oct_err = w; return code; };
+    if (!dim || !n_out || (nf && !footholds) || (capacity && !centers_out)) return fail(LRM_EINVAL, "null argument");
+    LrmOctreeSettings st;
+    if (st_in) st = *st_in;
+    else lrm_octree_default_settings(&st);
+    if (st.leg_count < 1 || st.leg_count > LRM_MAX_LEGS || st.leg_number_for_stab > st.leg_count || st.max_depth < 0 ||
+        st.angle_sample[0] < 1 || st.angle_sample[1] < 1 || st.angle_sample[2] < 1)
+        return fail(LRM_EINVAL, "bad octree settings");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LRM_ENODEV, "no HIP device");
+#define OCT_TRY(expr, where)                                                   \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            g_oct_err = std::string(where) + ": " + hipGetErrorString(e_);     \
+            cleanup();                                                         \
+            return (e_ == hipErrorOutOfMemory) ? LRM_ENOMEM : LRM_ENODEV;      \
+        }                                                                      \
+    } while (0)
+    float *d_f = nullptr;
+    LrmCompiledLeg* d_legs = nullptr;
+    OctChild* d_children = nullptr;
+    uint32_t* d_flags = nullptr;
+    size_t children_cap = 0;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    auto cleanup = [&]() {
+        if (d_f) (void)hipFree(d_f);
+        if (d_legs) (void)hipFree(d_legs);
+        if (d_children) (void)hipFree(d_children);
+        if (d_flags) (void)hipFree(d_flags);
+        if (ev_a) (void)hipEventDestroy(ev_a);
+        if (ev_b) (void)hipEventDestroy(ev_b);
+    };
+
+    // footholds as SoA on the device
+    std::vector<float> soa(3 * (nf ? nf : 1));
+    for (size_t i = 0; i < nf; i++) {
+        soa[i] = footholds[3 * i];
+        soa[nf + i] = footholds[3 * i + 1];
+        soa[2 * nf + i] = footholds[3 * i + 2];
+    }
+    OCT_TRY(hipMalloc(&d_f, soa.size() * sizeof(float)), "hipMalloc gpu_in.elements");
+    OCT_TRY(hipMemcpy(d_f, soa.data(), soa.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy gpu_in.elements");
+
+    // compiled legs for every (orientation sample, mounted leg)
+    const int n_angles_max = st.angle_sample[0] * st.angle_sample[1] * st.angle_sample[2];
+    std::vector<LrmCompiledLeg> legs((size_t)n_angles_max * st.leg_count);
+    bool all_fast = true;
+    for (int a = 0; a < n_angles_max; a++) {
+        const Quat q = quat_from_angle_index((unsigned)a, st);
+        const float qa[4] = {q.x, q.y, q.z, q.w};
+        for (int l = 0; l < st.leg_count; l++) {
+            LrmLegDimensions leg = *dim;
+            leg.body_angle = st.leg_mount[l]; // several_leg_octree.cu:94
+            lrm_compile_leg(leg, qa, 1, &legs[(size_t)a * st.leg_count + l]);
+            all_fast = all_fast && legs[(size_t)a * st.leg_count + l].fast_ok;
+        }
+    }
+    const bool fast = all_fast && lrm_get_mode() == LRM_MODE_FAST;
+    OCT_TRY(hipMalloc(&d_legs, legs.size() * sizeof(LrmCompiledLeg)), "hipMalloc legs");
+    OCT_TRY(hipMemcpy(d_legs, legs.data(), legs.size() * sizeof(LrmCompiledLeg), hipMemcpyHostToDevice), "hipMemcpy legs");
+    OCT_TRY(hipEventCreate(&ev_a), "hipEventCreate");
+    OCT_TRY(hipEventCreate(&ev_b), "hipEventCreate");
+
+    std::vector<Node> nodes(1);
+    for (int i = 0; i < 3; i++) {
+        nodes[0].c[i] = st.box_center[i];
+        nodes[0].h[i] = st.box_size[i];
+    }
+    nodes[0].raw = true;
+    const float reach_len = dim->body + dim->coxa_length + dim->femur_length + dim->tibia_length;
+    std::vector<int> expand{0}; // raw nodes to refine in this iteration
+    float total_ms = 0.f;
+    for (int depth = 0; depth < st.max_depth && !expand.empty(); depth++) {
+        std::vector<OctChild> level;
+        std::vector<int> level_nodes;
+        for (int pi : expand) {
+            const int first = (int)nodes.size();
+            nodes.resize(nodes.size() + 8);
+            Node& parent = nodes[pi];
+            parent.first_child = first;
+            const bool rot = parent.h[0] < st.enable_rot_below; // several_leg_octree.cu:52
+            for (unsigned ci = 0; ci < 8; ci++) {
+                Node& n = nodes[first + ci];
+                int missing = 0;
+                if (!create_child_box(parent, ci, st.min_box, &n, &missing)) { // several_leg_octree.cu:331-339
+                    n.dead = n.leaf = n.validity = n.on_edge = true;
+                    n.raw = false;
+                    std::memset(n.c, 0, sizeof n.c);
+                    std::memset(n.h, 0, sizeof n.h);
+                } else if (3 - missing <= 0) { // :342-347
+                    n.leaf = true;
+                    n.raw = false;
+                } else {                       // :348-353
+                    n.leaf = false;
+                    n.raw = true;
+                }
+                OctChild oc;
+                std::memcpy(oc.c, n.c, sizeof oc.c);
+                std::memcpy(oc.h, n.h, sizeof oc.h);
+                std::memcpy(oc.ph, parent.h, sizeof oc.ph);
+                oc.margin = rot ? 0.f : st.enable_rot_below / 3;
+                oc.n_angles = rot ? n_angles_max : 1;
+                oc.parent_valid = parent.validity;
+                oc.skip = n.validity; // dead quadrants are "valid" and skipped (:58-61)
+                oc.pad = 0;
+                level.push_back(oc);
+                level_nodes.push_back(first + ci);
+            }
+            nodes[pi].raw = false;
+        }
+        const size_t nc = level.size();
+        if (nc > children_cap) {
+            if (d_children) (void)hipFree(d_children);
+            if (d_flags) (void)hipFree(d_flags);
+            d_children = nullptr;
+            d_flags = nullptr;
+            OCT_TRY(hipMalloc(&d_children, nc * sizeof(OctChild)), "hipMalloc children");
+            OCT_TRY(hipMalloc(&d_flags, nc * sizeof(uint32_t)), "hipMalloc flags");
+            children_cap = nc;
+        }
+        OCT_TRY(hipMemcpy(d_children, level.data(), nc * sizeof(OctChild), hipMemcpyHostToDevice), "hipMemcpy children");
+        OCT_TRY(hipMemset(d_flags, 0, nc * sizeof(uint32_t)), "hipMemset flags");
+        std::vector<uint32_t> flags(nc, 0);
+        if (nf) {
+            size_t gx = (nf + kOctBlock - 1) / kOctBlock;
+            if (gx > 1024) gx = 1024;
+            const dim3 grid((unsigned)gx, (unsigned)nc);
+            OCT_TRY(hipEventRecord(ev_a, nullptr), "hipEventRecord");
+            if (fast)
+                hipLaunchKernelGGL(oct_validity_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
+                                   d_f + 2 * nf, nf, d_legs, st.leg_count, st.leg_number_for_stab, reach_len,
+                                   st.convex_radius * st.convex_radius, d_flags);
+            else
+                hipLaunchKernelGGL(oct_validity_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
+                                   d_f + 2 * nf, nf, d_legs, st.leg_count, st.leg_number_for_stab, reach_len,
+                                   st.convex_radius * st.convex_radius, d_flags);
+            OCT_TRY(hipGetLastError(), "Kernel launch");
+            OCT_TRY(hipEventRecord(ev_b, nullptr), "hipEventRecord");
+            OCT_TRY(hipMemcpy(flags.data(), d_flags, nc * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy flags");
+            float e = 0.f;
+            OCT_TRY(hipEventElapsedTime(&e, ev_a, ev_b), "hipEventElapsedTime");
+            total_ms += e;
+        }
+        // several_leg_octree.cu:134-150, with global ORs
+        std::vector<int> next;
+        for (size_t k = 0; k < nc; k++) {
+            Node& n = nodes[level_nodes[k]];
+            if (level[k].skip) continue;
+            if (flags[k] & 1u) n.validity = true;
+            if (flags[k] & 2u) n.leaf = true;
+            if ((flags[k] & 4u) && !(flags[k] & 2u)) n.on_edge = true;
+        }
+        // the next host iteration descends (branchKernel "goDeeper", :296-312): a child that is not on
+        // an edge becomes a leaf, the others are refined
+        if (depth + 1 < st.max_depth) {
+            for (size_t k = 0; k < nc; k++) {
+                Node& n = nodes[level_nodes[k]];
+                if (!n.on_edge) n.leaf = true;
+                if (!n.leaf) next.push_back(level_nodes[k]);
+            }
+        }
+        expand.swap(next);
+    }
+    // extractValidAsArray / fill_recus, octree_util.cu:128-180: depth first, child order
+    size_t count = 0;
+    std::vector<int> stack{0};
+    // iterative DFS that visits children in index order
+    struct Frame { int node; int next; };
+    std::vector<Frame> st_frames{{0, 0}};
+    while (!st_frames.empty()) {
+        Frame& fr = st_frames.back();
+        const Node& n = nodes[fr.node];
+        if (n.first_child < 0 || fr.next >= 8) {
+            st_frames.pop_back();
+            continue;
+        }
+        const int ci = n.first_child + fr.next++;
+        const Node& c = nodes[ci];
+        const bool endpoint = !(c.leaf || c.raw || c.dead);
+        const bool valid = !c.dead && (c.leaf || c.raw) && c.validity;
+        if (endpoint) st_frames.push_back(Frame{ci, 0});
+        else if (valid) {
+            if (count < capacity) std::memcpy(centers_out + 3 * count, c.c, 3 * sizeof(float));
+            count++;
+        }
+    }
+    *n_out = count;
+    if (ms) *ms = total_ms;
+    cleanup();
+#undef OCT_TRY
+    if (count > capacity) return fail(LRM_EINVAL, "output capacity too small (n_out holds the required count)");
+    return LRM_OK;
+}
+
+} // extern "C"

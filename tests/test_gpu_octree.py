@@ -1,0 +1,75 @@
+"""GPU parity of the level-synchronous octree (csrc/lrm_octree.hip) against the brute-force
+restatement tests/octree_oracle.py.  Parity is pinned by composition only (see that file)."""
+import numpy as np
+import pytest
+
+from octree_oracle import apply_oct as oracle_apply_oct
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["strict", "fast"])
+def mode(request, lrm):
+    lrm.set_mode(lrm.MODE_FAST if request.param == "fast" else lrm.MODE_STRICT)
+    yield request.param
+    lrm.set_mode(lrm.MODE_FAST)
+
+
+def footholds(n, seed, spread=600.0):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(-spread, spread, (n, 2))
+    z = 20 * np.sin(xy[:, 0] / 120) + rng.normal(0, 4, n) - 150
+    return np.column_stack([xy, z]).astype(np.float32)
+
+
+def settings(lrm, half, depth, stab=4, legs=4, mounts=None, rot_below=50.0):
+    st = lrm.octree_default_settings()
+    for i in range(3):
+        st.box_size[i] = half
+    st.max_depth = depth
+    st.leg_number_for_stab = stab
+    st.leg_count = legs
+    st.enable_rot_below = rot_below
+    if mounts is not None:
+        for i, m in enumerate(mounts):
+            st.leg_mount[i] = m
+    return st
+
+
+@pytest.mark.parametrize("half,depth,stab,rot_below", [
+    (5000.0, 1, 4, 50.0),     # the committed configuration (settings.h): one level, rotations never active
+    (400.0, 4, 1, 50.0),      # down to boxes below MINBOXSIZE: dead quadrants and unsplittable leaves
+    (800.0, 3, 2, 50.0),
+    (300.0, 3, 1, 400.0),     # small root with the 27 orientation samples active from the first level
+])
+def test_apply_oct_matches_bruteforce(lrm, oracle, half, depth, stab, rot_below):
+    f = footholds(160, seed=int(half) + depth)
+    dim = lrm.get_M2_leg(0.0)
+    st = settings(lrm, half, depth, stab=stab, rot_below=rot_below)
+    got, ms = lrm.apply_oct(f, dim, st)
+    want, n_nodes = oracle_apply_oct(oracle, f, dim, st)
+    assert ms >= 0
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if stab <= 2 and depth >= 3:
+        assert len(want) > 0 and n_nodes > 9  # the refinement actually happened
+
+
+def test_apply_oct_defaults_and_capacity(lrm, oracle):
+    f = footholds(64, seed=5)
+    dim = lrm.get_moonbot_leg(0.0)
+    got, _ = lrm.apply_oct(f, dim)  # settings.h as committed
+    want, _ = oracle_apply_oct(oracle, f, dim, lrm.octree_default_settings())
+    assert np.array_equal(got, want)
+    # capacity too small -> error code and required size
+    import ctypes as C
+    st = settings(lrm, 800.0, 3, stab=1)
+    full, _ = lrm.apply_oct(f, dim, st)
+    if len(full) > 1:
+        out = np.zeros((1, 3), np.float32)
+        n_out = C.c_size_t(0)
+        rc = lrm.lib().lrm_apply_oct(f.ctypes.data_as(C.c_void_p), len(f), dim.ctypes.data_as(C.c_void_p), C.addressof(st),
+                                     out.ctypes.data_as(C.c_void_p), 1, C.addressof(n_out), None)
+        assert rc == -1 and n_out.value == len(full)
+    # no footholds: nothing is valid
+    empty, _ = lrm.apply_oct(np.zeros((0, 3), np.float32), dim, st)
+    assert len(empty) == 0

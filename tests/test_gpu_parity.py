@@ -183,3 +183,43 @@ def test_device_sqrt_and_div_are_correctly_rounded(torch_cuda, lrm, oracle):
     want_d, want_v = oracle.dist(pts, leg, (0.99, 0.02, -0.1, 0.03))
     assert np.array_equal(v.cpu().numpy(), want_v)
     assert bits_equal(d.cpu().numpy().T, want_d).all()
+
+
+def test_random_legs_including_filter_ineligible_ones(lrm, oracle, torch_cuda):
+    """Random leg geometries and orientations; some legs (yaw limits beyond 90 degrees) are outside
+    the filter's eligibility and must silently take the strict kernels: results identical anyway."""
+    rng = np.random.default_rng(7)
+    pts = random_cloud(150000, seed=3)
+    x, y, z = soa(torch_cuda, pts)
+    for trial in range(10):
+        coxa_deg = rng.uniform(30, 80) if trial % 3 else rng.uniform(95, 150)  # every third: ineligible
+        leg = lrm.leg_factory(rng.uniform(-3, 3), rng.uniform(80, 250), rng.uniform(-60, 30), rng.uniform(30, 90),
+                              rng.uniform(90, 160), rng.uniform(90, 170), coxa_deg, rng.uniform(60, 100),
+                              rng.uniform(90, 140), rng.uniform(-20, 10), rng.uniform(-20, 10))
+        q = rng.normal(size=4).astype(np.float32)
+        q[0] += 3.0
+        m = lrm.device.reach(x, y, z, leg, q)
+        m2, d = lrm.device.reach_dist(x, y, z, leg, q)
+        torch_cuda.cuda.synchronize()
+        want_m = oracle.reach(pts, leg, q)
+        want_d, _ = oracle.dist(pts, leg, q)
+        assert np.array_equal(m.cpu().numpy(), want_m) and np.array_equal(m2.cpu().numpy(), want_m)
+        assert bits_equal(d.cpu().numpy().T, want_d).all()
+
+
+def test_non_finite_and_extreme_inputs(lrm, oracle, torch_cuda):
+    """nan / inf / huge / denormal coordinates: same bytes and same floats (nan == nan) as the oracle."""
+    vals = np.array([0.0, -0.0, 1e-42, -1e-42, 1e-30, 300.0, -300.0, 1e7, -1e7, 1e30, 3e38, np.inf, -np.inf, np.nan],
+                    np.float32)
+    g = np.stack(np.meshgrid(vals, vals, vals, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    x, y, z = soa(torch_cuda, g)
+    for leg in (lrm.get_M2_leg(0.3), lrm.get_moonbot_leg(0.0)):
+        for q in (None, (0.95, 0.1, -0.2, 0.15)):
+            qq = (1, 0, 0, 0) if q is None else q
+            m = lrm.device.reach(x, y, z, leg, q)
+            d, v = lrm.device.dist(x, y, z, leg, q)
+            torch_cuda.cuda.synchronize()
+            want_d, want_v = oracle.dist(g, leg, qq)
+            assert np.array_equal(m.cpu().numpy(), oracle.reach(g, leg, qq))
+            assert np.array_equal(v.cpu().numpy(), want_v)
+            assert bits_equal(d.cpu().numpy().T, want_d).all()
