@@ -36,22 +36,34 @@ def settings(lrm, half, depth, stab=4, legs=4, mounts=None, rot_below=50.0):
     return st
 
 
-@pytest.mark.parametrize("half,depth,stab,rot_below", [
-    (5000.0, 1, 4, 50.0),     # the committed configuration (settings.h): one level, rotations never active
-    (400.0, 4, 1, 50.0),      # down to boxes below MINBOXSIZE: dead quadrants and unsplittable leaves
-    (800.0, 3, 2, 50.0),
-    (300.0, 3, 1, 400.0),     # small root with the 27 orientation samples active from the first level
+@pytest.mark.parametrize("half,depth,stab,rot_below,deep", [
+    (5000.0, 1, 4, 50.0, False),   # the committed configuration (settings.h): one level, rotations never active
+    (400.0, 4, 3, 50.0, True),     # down to boxes below MINBOXSIZE: dead quadrants and unsplittable leaves
+    (400.0, 4, 4, 50.0, True),     # LegNumberForStab = LegCount as committed: deep tree, nothing valid
+    (800.0, 3, 2, 50.0, True),
+    (300.0, 3, 1, 400.0, False),   # small root with the 27 orientation samples active from the first level
 ])
-def test_apply_oct_matches_bruteforce(lrm, oracle, half, depth, stab, rot_below):
-    f = footholds(160, seed=int(half) + depth)
+def test_apply_oct_matches_bruteforce(lrm, oracle, half, depth, stab, rot_below, deep):
+    f = footholds(160, seed=404)
     dim = lrm.get_M2_leg(0.0)
     st = settings(lrm, half, depth, stab=stab, rot_below=rot_below)
     got, ms = lrm.apply_oct(f, dim, st)
     want, n_nodes = oracle_apply_oct(oracle, f, dim, st)
     assert ms >= 0
     assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
-    if stab <= 2 and depth >= 3:
-        assert len(want) > 0 and n_nodes > 9  # the refinement actually happened
+    if deep:
+        assert n_nodes > 200  # the refinement actually happened
+    if stab == 3:
+        assert len(want) > 10
+
+
+def test_apply_oct_two_legs_many_valid_leaves(lrm, oracle):
+    f = footholds(160, seed=404)
+    dim = lrm.get_M2_leg(0.0)
+    st = settings(lrm, 400.0, 5, stab=2, legs=2, mounts=(0.0, 0.3))
+    got, _ = lrm.apply_oct(f, dim, st)
+    want, n_nodes = oracle_apply_oct(oracle, f, dim, st)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and len(want) > 100 and n_nodes > 500
 
 
 def test_apply_oct_defaults_and_capacity(lrm, oracle):
