@@ -20,7 +20,7 @@ namespace {
 
 constexpr int kBlock = 256;
 #ifndef LRM_DIST_MIN_WAVES
-#define LRM_DIST_MIN_WAVES 1
+#define LRM_DIST_MIN_WAVES 4 // <= 128 VGPRs (4 waves/SIMD): measured 5 % faster than the unconstrained 141
 #endif
 #ifndef LRM_REACH_MIN_WAVES
 #define LRM_REACH_MIN_WAVES 1
