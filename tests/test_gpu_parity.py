@@ -223,3 +223,35 @@ def test_non_finite_and_extreme_inputs(lrm, oracle, torch_cuda):
             assert np.array_equal(m.cpu().numpy(), oracle.reach(g, leg, qq))
             assert np.array_equal(v.cpu().numpy(), want_v)
             assert bits_equal(d.cpu().numpy().T, want_d).all()
+
+
+def test_config4_cloud_1e8_points_on_one_gpu(lrm, oracle, torch_cuda, mode):
+    """BASELINE config 4's whole 1e8-point cloud on ONE GPU (the multi-GPU job gives each rank an
+    eighth of it): reach mask + bit words, checked exactly against the oracle on three 1e6-point
+    windows and through size-independent properties everywhere (bytes are 0/1, bit words unpack to
+    the bytes, popcount = byte sum, a shifted window of the same points gives the same answers)."""
+    if mode == "strict":
+        pytest.skip("the 1e8-point run is done once, in the default mode")
+    n = 100_000_000
+    rng = np.random.default_rng(4)
+    host = np.empty((3, n), np.float32)
+    lo = np.array([-200, -500, -500], np.float32)
+    hi = np.array([700, 500, 300], np.float32)
+    for s0 in range(0, n, 10_000_000):
+        host[:, s0:s0 + 10_000_000] = (rng.random((10_000_000, 3), dtype=np.float32) * (hi - lo) + lo).T
+    dev = torch_cuda.from_numpy(host).cuda()
+    leg = lrm.get_M2_leg(0.0)
+    m, bits = lrm.device.reach(dev[0], dev[1], dev[2], leg, want_bits=True)
+    torch_cuda.cuda.synchronize()
+    mask = m.cpu().numpy()
+    assert mask.max() <= 1
+    b = bits.cpu().numpy().view(np.uint8)
+    assert np.array_equal(np.unpackbits(b, bitorder="little")[:n], mask)
+    for w0 in (0, 49_999_937, n - 1_000_000):
+        pts = np.ascontiguousarray(host[:, w0:w0 + 1_000_000].T)
+        assert np.array_equal(mask[w0:w0 + 1_000_000], oracle.reach(pts, leg))
+    # an unaligned window of the same buffer (scalar kernel) must reproduce the same bytes
+    w0, wn = 12_345_677, 3_000_001
+    m2 = lrm.device.reach(dev[0][w0:w0 + wn], dev[1][w0:w0 + wn], dev[2][w0:w0 + wn], leg)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(m2.cpu().numpy(), mask[w0:w0 + wn])
