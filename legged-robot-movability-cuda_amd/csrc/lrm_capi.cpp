@@ -336,9 +336,22 @@ int leg_slot(LrmCompiledLeg** out) {
 }
 } // namespace
 
+namespace {
+int reach_any_impl(const float* bx, const float* by, const float* bz, size_t nb, const float* tx, const float* ty,
+                   const float* tz, size_t nt, const LrmLegDimensions* legs, size_t nlegs, const float* quat,
+                   const uint8_t* body_active, uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream);
+}
+
 int lrm_reach_any_dev(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
                       const float* ty, const float* tz, size_t nt, const LrmLegDimensions* legs, size_t nlegs,
                       const float* quat, uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream) {
+    return reach_any_impl(bx, by, bz, nb, tx, ty, tz, nt, legs, nlegs, quat, nullptr, out_leg_body, all_legs_out, stream);
+}
+
+namespace {
+int reach_any_impl(const float* bx, const float* by, const float* bz, size_t nb, const float* tx, const float* ty,
+                   const float* tz, size_t nt, const LrmLegDimensions* legs, size_t nlegs, const float* quat,
+                   const uint8_t* body_active, uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream) {
     if (!legs || nlegs == 0 || nlegs > LRM_MAX_LEGS) return fail(LRM_EINVAL, "nlegs must be 1..LRM_MAX_LEGS");
     if (!out_leg_body || (nb && (!bx || !by || !bz)) || (nt && (!tx || !ty || !tz)))
         return fail(LRM_EINVAL, "null argument");
@@ -358,10 +371,11 @@ int lrm_reach_any_dev(const float* bx, const float* by, const float* bz, size_t 
         rc = tile_boxes(nt, &boxes);
         if (rc != LRM_OK) return rc;
     }
-    HIP_TRY(lrm_launch_reach_any(bx, by, bz, nb, tx, ty, tz, nt, dev_legs, (int)nlegs, boxes, out_leg_body,
+    HIP_TRY(lrm_launch_reach_any(bx, by, bz, nb, tx, ty, tz, nt, dev_legs, (int)nlegs, boxes, body_active, out_leg_body,
                                  all_legs_out, fast, (hipStream_t)stream), "reach_any launch");
     return LRM_OK;
 }
+} // namespace
 
 int lrm_any_in_sphere_dev(const float* cx, const float* cy, const float* cz, size_t nc, const float* tx,
                           const float* ty, const float* tz, size_t nt, float radius, uint8_t* out, void* stream) {
@@ -430,15 +444,17 @@ int lrm_dbg_fast_host(const float* xyz, size_t n, const LrmLegDimensions* leg, c
 }
 
 // robot_full_struct's pipeline (several_leg.cu:326-877) with masks instead of thrust stream
-// compaction.  reference_culls != 0 adds the estimator's culls:
+// compaction, resident on the device from the first upload to the final mask.
+// reference_culls != 0 adds the estimator's culls:
 //   once      eliminateAlwaysColliding (sphere r = 60, :413-440), eliminateFarBody (r = 400, :442-474),
 //             eliminateFarTarget (r = 400 around the surviving bodies, :476-502)
 //   per quat  eliminateFarAndColliding (:504-559): keep a body iff some target lies in the big
 //             cylinder of (rotated) leg 0 and none in the body cylinder (r = body, z in (-110, 250))
-// For each orientation bodies and targets are rotated by the quaternion (rotateData :401-411, on
-// the host copies here), the legs' limits are rotated (rotateLegsLimits :743-760), every leg must
-// find a reachable target (eliminateUnreachable :707-741, generalised from 4 to nlegs legs), and a
-// body accepted by one orientation is not tested again (flipWorkingSide :396-399).
+// For each orientation bodies and targets are rotated by the quaternion (rotateData :401-411: a
+// kernel with the strict qtRotate arithmetic), the legs' limits are rotated (rotateLegsLimits
+// :743-760, host), every leg must find a reachable target (eliminateUnreachable :707-741,
+// generalised from 4 to nlegs legs), and a body accepted by one orientation is not tested again
+// (flipWorkingSide :396-399: an `active` byte per body instead of partitioning).
 int lrm_positionability(const float* bodies, size_t nb, const float* targets, size_t nt,
                         const LrmLegDimensions* legs, size_t nlegs, const float* quats, size_t nquat,
                         int reference_culls, uint8_t* body_mask_out, float* ms) {
@@ -448,44 +464,50 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LRM_ENODEV, "no HIP device");
     if (nb == 0) return LRM_OK;
-    std::memset(body_mask_out, 0, nb);
-    float total_ms = 0.f;
     Events ev;
     HIP_TRY(hipEventCreate(&ev.a), "hipEventCreate");
     HIP_TRY(hipEventCreate(&ev.b), "hipEventCreate");
-    DevBuf d_b, d_t, d_m1, d_m2, d_leg_body, d_all;
-    HIP_TRY(d_b.alloc(3 * nb * sizeof(float)), "hipMalloc bodies");
-    HIP_TRY(d_t.alloc(3 * (nt + nb) * sizeof(float)), "hipMalloc targets");
+    const size_t pb = (nb + 3) & ~(size_t)3, pt = ((nt ? nt : 1) + 3) & ~(size_t)3; // keep component arrays aligned
+    DevBuf d_b0, d_t0, d_b, d_t, d_m1, d_m2, d_leg_body, d_all, d_active, d_accepted, d_rot;
+    HIP_TRY(d_b0.alloc(3 * pb * sizeof(float)), "hipMalloc bodies");
+    HIP_TRY(d_b.alloc(3 * pb * sizeof(float)), "hipMalloc bodies");
+    HIP_TRY(d_t0.alloc(3 * pt * sizeof(float)), "hipMalloc targets");
+    HIP_TRY(d_t.alloc(3 * pt * sizeof(float)), "hipMalloc targets");
     HIP_TRY(d_m1.alloc(nb > nt ? nb : nt), "hipMalloc mask");
     HIP_TRY(d_m2.alloc(nb > nt ? nb : nt), "hipMalloc mask");
     HIP_TRY(d_leg_body.alloc(nlegs * nb), "hipMalloc leg results");
     HIP_TRY(d_all.alloc(nb), "hipMalloc body results");
+    HIP_TRY(d_active.alloc(nb), "hipMalloc active");
+    HIP_TRY(d_accepted.alloc(nb), "hipMalloc accepted");
+    HIP_TRY(d_rot.alloc(sizeof(LrmCompiledLeg)), "hipMalloc rotation");
 
-    // SoA upload helper: idx selects rows of an AoS array (optionally rotated by rot's fwd_rot)
+    // AoS host -> SoA device (component stride `pad`)
     std::vector<float> stage;
-    auto upload = [&](const float* aos, const std::vector<size_t>& idx, const LrmCompiledLeg* rot, void* dst) -> hipError_t {
-        const size_t m = idx.size();
-        stage.resize(3 * (m ? m : 1));
+    auto upload = [&](const float* aos, const size_t* idx, size_t m, size_t pad, void* dst) -> hipError_t {
+        stage.assign(3 * pad, 0.f);
         for (size_t k = 0; k < m; k++) {
-            LrmVec3 v{aos[3 * idx[k]], aos[3 * idx[k] + 1], aos[3 * idx[k] + 2]};
-            if (rot) v = lrm_qrot(rot->fwd_rot, v);
-            stage[k] = v.x; stage[m + k] = v.y; stage[2 * m + k] = v.z;
+            const size_t i = idx ? idx[k] : k;
+            stage[k] = aos[3 * i];
+            stage[pad + k] = aos[3 * i + 1];
+            stage[2 * pad + k] = aos[3 * i + 2];
         }
-        return hipMemcpy(dst, stage.data(), 3 * m * sizeof(float), hipMemcpyHostToDevice);
+        return hipMemcpy(dst, stage.data(), 3 * pad * sizeof(float), hipMemcpyHostToDevice);
     };
-    std::vector<uint8_t> h1(nb > nt ? nb : nt), h2(nb > nt ? nb : nt);
-    std::vector<size_t> active(nb), kept_t(nt);
-    for (size_t i = 0; i < nb; i++) active[i] = i;
-    for (size_t i = 0; i < nt; i++) kept_t[i] = i;
+    HIP_TRY(upload(bodies, nullptr, nb, pb, d_b0.p), "hipMemcpy bodies");
+    size_t mt = nt; // targets kept after the one-time cull
+    if (nt) HIP_TRY(upload(targets, nullptr, nt, pt, d_t0.p), "hipMemcpy targets");
+    float* B0 = d_b0.as<float>();
+    float* T0 = d_t0.as<float>();
+    float* B = d_b.as<float>();
+    float* T = d_t.as<float>();
+    std::vector<uint8_t> active(nb, 1), h1(nb > nt ? nb : nt), h2(nb);
+    float total_ms = 0.f;
+    HIP_TRY(hipMemset(d_accepted.p, 0, nb), "hipMemset accepted");
 
     if (reference_culls && nt) {
-        HIP_TRY(upload(bodies, active, nullptr, d_b.p), "hipMemcpy bodies");
-        HIP_TRY(upload(targets, kept_t, nullptr, d_t.p), "hipMemcpy targets");
-        const float* B = d_b.as<float>();
-        const float* T = d_t.as<float>();
         HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
-        int rc = lrm_any_in_sphere_dev(B, B + nb, B + 2 * nb, nb, T, T + nt, T + 2 * nt, nt, 60.f, d_m1.as<uint8_t>(), nullptr);
-        if (rc == LRM_OK) rc = lrm_any_in_sphere_dev(B, B + nb, B + 2 * nb, nb, T, T + nt, T + 2 * nt, nt, 400.f, d_m2.as<uint8_t>(), nullptr);
+        int rc = lrm_any_in_sphere_dev(B0, B0 + pb, B0 + 2 * pb, nb, T0, T0 + pt, T0 + 2 * pt, nt, 60.f, d_m1.as<uint8_t>(), nullptr);
+        if (rc == LRM_OK) rc = lrm_any_in_sphere_dev(B0, B0 + pb, B0 + 2 * pb, nb, T0, T0 + pt, T0 + 2 * pt, nt, 400.f, d_m2.as<uint8_t>(), nullptr);
         if (rc != LRM_OK) return rc;
         HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
         HIP_TRY(hipMemcpy(h1.data(), d_m1.p, nb, hipMemcpyDeviceToHost), "hipMemcpy mask");
@@ -494,43 +516,43 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
         HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
         total_ms += e;
         std::vector<size_t> alive;
-        for (size_t i = 0; i < nb; i++)
-            if (h1[i] == 0 && h2[i] != 0) alive.push_back(i);
-        active.swap(alive);
-        // eliminateFarTarget: targets with a surviving body within 400
-        if (!active.empty()) {
-            const size_t na = active.size();
-            HIP_TRY(upload(bodies, active, nullptr, d_b.p), "hipMemcpy bodies");
-            const float* A = d_b.as<float>();
+        for (size_t i = 0; i < nb; i++) {
+            active[i] = (h1[i] == 0 && h2[i] != 0) ? 1 : 0;
+            if (active[i]) alive.push_back(i);
+        }
+        // eliminateFarTarget: keep the targets with a surviving body within 400 (compacted once, on the host)
+        mt = 0;
+        if (!alive.empty()) {
+            const size_t na = alive.size(), pa = (na + 3) & ~(size_t)3;
+            HIP_TRY(upload(bodies, alive.data(), na, pa, d_b.p), "hipMemcpy bodies");
             HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
-            rc = lrm_any_in_sphere_dev(T, T + nt, T + 2 * nt, nt, A, A + na, A + 2 * na, na, 400.f, d_m1.as<uint8_t>(), nullptr);
+            rc = lrm_any_in_sphere_dev(T0, T0 + pt, T0 + 2 * pt, nt, B, B + pa, B + 2 * pa, na, 400.f, d_m1.as<uint8_t>(), nullptr);
             if (rc != LRM_OK) return rc;
             HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
             HIP_TRY(hipMemcpy(h1.data(), d_m1.p, nt, hipMemcpyDeviceToHost), "hipMemcpy mask");
             HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
             total_ms += e;
-            std::vector<size_t> kt;
+            std::vector<size_t> kept;
             for (size_t i = 0; i < nt; i++)
-                if (h1[i]) kt.push_back(i);
-            kept_t.swap(kt);
-        } else {
-            kept_t.clear();
+                if (h1[i]) kept.push_back(i);
+            mt = kept.size();
+            if (mt) HIP_TRY(upload(targets, kept.data(), mt, pt, d_t0.p), "hipMemcpy targets");
         }
     }
+    HIP_TRY(hipMemcpy(d_active.p, active.data(), nb, hipMemcpyHostToDevice), "hipMemcpy active");
 
-    for (size_t qi = 0; qi < nquat && !active.empty(); qi++) {
+    HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
+    for (size_t qi = 0; qi < nquat; qi++) {
         const float* q = quats + 4 * qi;
         LrmCompiledLeg rot;
         LrmLegDimensions dummy{};
         lrm_compile_leg(dummy, q, 0, &rot); // only for fwd_rot = qtRotate(q, .)
         LrmLegDimensions rl[LRM_MAX_LEGS];
         for (size_t l = 0; l < nlegs; l++) lrm_host_rotate_leg_data(q, legs[l], &rl[l]);
-        const size_t na = active.size(), mt = kept_t.size();
-        HIP_TRY(upload(bodies, active, &rot, d_b.p), "hipMemcpy bodies");
-        HIP_TRY(upload(targets, kept_t, &rot, d_t.p), "hipMemcpy targets");
-        const float* B = d_b.as<float>();
-        const float* T = d_t.as<float>();
-        HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
+        // the previous iteration's kernels are done reading d_rot before this blocking copy returns
+        HIP_TRY(hipMemcpy(d_rot.p, &rot, sizeof rot, hipMemcpyHostToDevice), "hipMemcpy rotation");
+        HIP_TRY(lrm_launch_rotate_soa(B0, B0 + pb, B0 + 2 * pb, nb, d_rot.as<LrmCompiledLeg>(), B, B + pb, B + 2 * pb, nullptr), "rotate bodies");
+        if (mt) HIP_TRY(lrm_launch_rotate_soa(T0, T0 + pt, T0 + 2 * pt, mt, d_rot.as<LrmCompiledLeg>(), T, T + pt, T + 2 * pt, nullptr), "rotate targets");
         int rc = LRM_OK;
         if (reference_culls) {
             // eliminateFarAndColliding, several_leg.cu:504-525, with the rotated leg 0
@@ -542,35 +564,24 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
                                    d.femur_length * sinf(half_pi < d.max_angle_femur ? half_pi : d.max_angle_femur);
             const float plus_z_in = s_pitch * d.coxa_length + plus_abs;
             const float minus_z_in = s_pitch * d.coxa_length - d.femur_length - d.tibia_length;
-            rc = lrm_any_in_cylinder_dev(B, B + na, B + 2 * na, na, T, T + mt, T + 2 * mt, mt, radius_in, plus_z_in,
-                                         minus_z_in, d_m1.as<uint8_t>(), nullptr);
+            rc = lrm_any_in_cylinder_dev(B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, radius_in, plus_z_in, minus_z_in,
+                                         d_m1.as<uint8_t>(), nullptr);
             if (rc == LRM_OK)
-                rc = lrm_any_in_cylinder_dev(B, B + na, B + 2 * na, na, T, T + mt, T + 2 * mt, mt, d.body, 250.f, -110.f,
+                rc = lrm_any_in_cylinder_dev(B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, d.body, 250.f, -110.f,
                                              d_m2.as<uint8_t>(), nullptr);
             if (rc != LRM_OK) return rc;
         }
-        rc = lrm_reach_any_dev(B, B + na, B + 2 * na, na, T, T + mt, T + 2 * mt, mt, rl, nlegs, q,
-                               d_leg_body.as<uint8_t>(), d_all.as<uint8_t>(), nullptr);
+        rc = reach_any_impl(B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, rl, nlegs, q, d_active.as<uint8_t>(),
+                            d_leg_body.as<uint8_t>(), d_all.as<uint8_t>(), nullptr);
         if (rc != LRM_OK) return rc;
-        HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
-        HIP_TRY(hipEventSynchronize(ev.b), "reach_any");
-        float e = 0.f;
-        HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
-        total_ms += e;
-        std::vector<uint8_t> acc(na);
-        HIP_TRY(hipMemcpy(acc.data(), d_all.p, na, hipMemcpyDeviceToHost), "hipMemcpy result");
-        if (reference_culls) {
-            HIP_TRY(hipMemcpy(h1.data(), d_m1.p, na, hipMemcpyDeviceToHost), "hipMemcpy mask");
-            HIP_TRY(hipMemcpy(h2.data(), d_m2.p, na, hipMemcpyDeviceToHost), "hipMemcpy mask");
-            for (size_t k = 0; k < na; k++) acc[k] = acc[k] && h1[k] == 1 && h2[k] != 1;
-        }
-        std::vector<size_t> rest;
-        for (size_t k = 0; k < na; k++) {
-            if (acc[k]) body_mask_out[active[k]] = 1;
-            else rest.push_back(active[k]);
-        }
-        active.swap(rest);
+        HIP_TRY(lrm_launch_sweep_update(d_all.as<uint8_t>(), d_m1.as<uint8_t>(), d_m2.as<uint8_t>(), reference_culls ? 1 : 0, nb,
+                                        d_active.as<uint8_t>(), d_accepted.as<uint8_t>(), nullptr), "sweep update");
     }
+    HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
+    HIP_TRY(hipMemcpy(body_mask_out, d_accepted.p, nb, hipMemcpyDeviceToHost), "hipMemcpy result");
+    float e = 0.f;
+    HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
+    total_ms += e;
     if (ms) *ms = total_ms;
     return LRM_OK;
 }

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
     const float* __restrict__ bx, const float* __restrict__ by, const float* __restrict__ bz, size_t nb,
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, size_t nt,
     const LrmCompiledLeg* __restrict__ legs, int nlegs, const float* __restrict__ boxes,
-    uint8_t* __restrict__ out, uint8_t* __restrict__ all_out) {
+    const uint8_t* __restrict__ body_active /* null = all */, uint8_t* __restrict__ out, uint8_t* __restrict__ all_out) {
     __shared__ float s_tx[kTargetTile], s_ty[kTargetTile], s_tz[kTargetTile];
     __shared__ float s_qx[kWaves][kQueue], s_qy[kWaves][kQueue], s_qz[kWaves][kQueue];
     __shared__ LrmCompiledLeg::LeanCircle s_lean[LRM_MAX_LEGS][16];
@@ -422,7 +422,8 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
 
     for (size_t group = blockIdx.x; group * kWaves < nb; group += gridDim.x) {
         const size_t b = group * kWaves + wave;
-        const bool live = b < nb;
+        const bool in_range = b < nb;
+        const bool live = in_range && (!body_active || body_active[b] != 0); // inactive bodies answer 0
         const LrmVec3 body = live ? LrmVec3{bx[b], by[b], bz[b]} : LrmVec3{0.f, 0.f, 0.f};
         uint32_t found = live ? 0u : all_found; // bit l: leg l has a reachable target
         int count = 0;                           // survivors waiting in this wave's queue
@@ -522,8 +523,41 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
           if (all_done) break;
         }
         if (count > 0 && found != all_found) process(count);
-        if (live && lane < nlegs) out[(size_t)lane * nb + b] = (found >> lane) & 1u;
-        if (live && lane == 0 && all_out) all_out[b] = (found == all_found) ? 1 : 0;
+        if (in_range && lane < nlegs) out[(size_t)lane * nb + b] = live ? ((found >> lane) & 1u) : 0;
+        if (in_range && lane == 0 && all_out) all_out[b] = (live && found == all_found) ? 1 : 0;
+    }
+}
+
+// rotateData (several_leg.cu:401-411): dst = qtRotate(q, src) with the strict coefficient form
+__global__ __launch_bounds__(kBlock) void rotate_soa_kernel(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                            const float* __restrict__ sz, size_t n, const LrmCompiledLeg* rot,
+                                                            float* __restrict__ dx, float* __restrict__ dy,
+                                                            float* __restrict__ dz) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const LrmVec3 r = lrm_qrot(rot->fwd_rot, LrmVec3{sx[i], sy[i], sz[i]});
+        dx[i] = r.x;
+        dy[i] = r.y;
+        dz[i] = r.z;
+    }
+}
+
+// One orientation of the estimator's pipeline folded into the running state (several_leg.cu:
+// 504-559 bring_together, :698-706 cleanAgregated, :396-399 flipWorkingSide): a body is accepted
+// when it is still active, passes the cylinder pair (if used) and every leg found a target.
+__global__ __launch_bounds__(kBlock) void sweep_update_kernel(const uint8_t* __restrict__ all_legs,
+                                                              const uint8_t* __restrict__ cyl_validate,
+                                                              const uint8_t* __restrict__ cyl_eliminate, int use_culls,
+                                                              size_t nb, uint8_t* __restrict__ active,
+                                                              uint8_t* __restrict__ accepted) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x; b < nb; b += stride) {
+        bool ok = active[b] != 0 && all_legs[b] != 0;
+        if (use_culls) ok = ok && cyl_validate[b] == 1 && cyl_eliminate[b] != 1;
+        if (ok) {
+            accepted[b] = 1;
+            active[b] = 0;
+        }
     }
 }
 
@@ -658,8 +692,8 @@ hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmComp
 
 hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
                                 const float* ty, const float* tz, size_t nt, const LrmCompiledLeg* legs_dev,
-                                int nlegs, float* tile_boxes, uint8_t* out_leg_body, uint8_t* all_legs_out, bool fast,
-                                hipStream_t st) {
+                                int nlegs, float* tile_boxes, const uint8_t* body_active, uint8_t* out_leg_body,
+                                uint8_t* all_legs_out, bool fast, hipStream_t st) {
     if (tile_boxes && nt) {
         hipLaunchKernelGGL(tile_aabb_kernel, dim3((unsigned)((nt + 1023) / 1024)), dim3(kBlock), 0, st, tx, ty, tz, nt, tile_boxes);
         hipError_t e = hipGetLastError();
@@ -668,8 +702,8 @@ hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* b
     size_t groups = (nb + kWaves - 1) / kWaves;
     if (groups > 256 * 16) groups = 256 * 16; // persistent over body groups beyond that
     const dim3 grid((unsigned)groups);
-    if (fast) hipLaunchKernelGGL(reach_any_kernel<true>, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev, nlegs, tile_boxes, out_leg_body, all_legs_out);
-    else hipLaunchKernelGGL(reach_any_kernel<false>, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev, nlegs, tile_boxes, out_leg_body, all_legs_out);
+    if (fast) hipLaunchKernelGGL(reach_any_kernel<true>, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev, nlegs, tile_boxes, body_active, out_leg_body, all_legs_out);
+    else hipLaunchKernelGGL(reach_any_kernel<false>, grid, dim3(kBlock), 0, st, bx, by, bz, nb, tx, ty, tz, nt, legs_dev, nlegs, tile_boxes, body_active, out_leg_body, all_legs_out);
     return hipGetLastError();
 }
 
@@ -689,5 +723,18 @@ hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, 
 hipError_t lrm_launch_exact_math(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs,
                                  hipStream_t st) {
     hipLaunchKernelGGL(exact_math_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, a, b, n, at2, sn, cs);
+    return hipGetLastError();
+}
+
+hipError_t lrm_launch_rotate_soa(const float* sx, const float* sy, const float* sz, size_t n, const LrmCompiledLeg* rot_dev,
+                                 float* dx, float* dy, float* dz, hipStream_t st) {
+    hipLaunchKernelGGL(rotate_soa_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, sx, sy, sz, n, rot_dev, dx, dy, dz);
+    return hipGetLastError();
+}
+
+hipError_t lrm_launch_sweep_update(const uint8_t* all_legs, const uint8_t* cyl_validate, const uint8_t* cyl_eliminate,
+                                   int use_culls, size_t nb, uint8_t* active, uint8_t* accepted, hipStream_t st) {
+    hipLaunchKernelGGL(sweep_update_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, st, all_legs, cyl_validate, cyl_eliminate,
+                       use_culls, nb, active, accepted);
     return hipGetLastError();
 }

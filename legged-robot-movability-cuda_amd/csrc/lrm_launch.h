@@ -17,9 +17,14 @@ hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmComp
 hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
                                 const float* ty, const float* tz, size_t nt, const LrmCompiledLeg* legs_dev,
                                 int nlegs, float* tile_boxes /* ntiles x 6 floats of workspace, or null */,
-                                uint8_t* out_leg_body, uint8_t* all_legs_out, bool fast, hipStream_t st);
+                                const uint8_t* body_active /* null = all */, uint8_t* out_leg_body,
+                                uint8_t* all_legs_out, bool fast, hipStream_t st);
 hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, const float* cz, size_t nc,
                                    const float* tx, const float* ty, const float* tz, size_t nt, float radius,
                                    float plus_z, float minus_z, uint8_t* out, hipStream_t st);
 hipError_t lrm_launch_exact_math(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs,
                                  hipStream_t st);
+hipError_t lrm_launch_rotate_soa(const float* sx, const float* sy, const float* sz, size_t n, const LrmCompiledLeg* rot_dev,
+                                 float* dx, float* dy, float* dz, hipStream_t st);
+hipError_t lrm_launch_sweep_update(const uint8_t* all_legs, const uint8_t* cyl_validate, const uint8_t* cyl_eliminate,
+                                   int use_culls, size_t nb, uint8_t* active, uint8_t* accepted, hipStream_t st);

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", type=int, default=0, help="verify this many random bodies against the oracle")
     ap.add_argument("--mode", choices=["strict", "fast"], default="fast")
+    ap.add_argument("--sweep", action="store_true",
+                    help="also time the whole robot_full_struct pipeline: 45 orientations + the reference culls")
     args = ap.parse_args()
     import torch
     import lrm_amd
@@ -57,6 +59,18 @@ def main():
         want = o.reach_any(bodies[idx], ground, legs)
         res["oracle_check"] = {"bodies": int(args.check), "seconds": time.time() - t0,
                                "identical": bool(np.array_equal(out.cpu().numpy()[:, idx], want))}
+    if args.sweep:
+        quats = workloads.reference_sweep_quats()
+        # scalar-first quaternions (qtRotate's convention) for a sweep in which poses are feasible
+        yaw = np.linspace(0, np.pi / 2, 5)
+        tilt = [-np.pi / 8, 0.0, np.pi / 8]
+        sane = np.array([[np.cos(a / 2) * np.cos(t / 2), 0, np.cos(a / 2) * np.sin(t / 2), np.sin(a / 2) * np.cos(t / 2)]
+                         for t in tilt for a in yaw] * 3, np.float32)
+        for name, qs in (("reference_quats", quats), ("scalar_first_quats", sane)):
+            t0 = time.time()
+            accepted, kms = lrm_amd.positionability(bodies, ground, legs[:4], qs, reference_culls=True)
+            res["sweep_" + name] = {"orientations": len(qs), "legs": 4, "kernel_ms": kms, "wall_s": time.time() - t0,
+                                    "accepted": int(accepted.sum())}
     print(json.dumps(res), flush=True)
 
 

@@ -116,3 +116,37 @@ def body_lattice(ground, n_bodies, voxel=50.0, clearance=(0.0, 350.0), seed=42):
 def hexapod(leg_factory, n_legs=6):
     """n_legs copies of one leg mounted every 2 pi / n_legs (several_leg.cpp:40-47 does 4)."""
     return np.stack([leg_factory(np.float32(2 * np.pi * k / n_legs)) for k in range(n_legs)])
+
+
+def reference_sweep_quats():
+    """The 45 orientations of robot_full_struct (several_leg.cu:814-857): roll, pitch in
+    {-pi/8, 0, pi/8}, yaw in {0, pi/8, pi/4, 3pi/8, pi/2}, quat = yaw * pitch * roll * init, built with
+    the reference's own quatFromVectAngle / qtMultiply (unified_math_cuda.cu.h:40-57), float32."""
+    f = np.float32
+
+    def from_axis(axis, angle):
+        s, c = f(np.sin(f(angle) / f(2), dtype=f)), f(np.cos(f(angle) / f(2), dtype=f))
+        ax = np.asarray(axis, f)
+        mag = f(np.sqrt(f(ax[0] * ax[0] + ax[1] * ax[1]) + ax[2] * ax[2]))
+        return np.array([s, c * ax[0] / mag, c * ax[1] / mag, c * ax[2] / mag], f)
+
+    def mul(a, b):  # (x, y, z, w) with w the scalar part, as qtMultiply
+        w = f(f(f(a[3] * b[3] - a[0] * b[0]) - a[1] * b[1]) - a[2] * b[2])
+        x = f(f(f(a[3] * b[0] + a[0] * b[3]) + a[1] * b[2]) - a[2] * b[1])
+        y = f(f(f(a[3] * b[1] - a[0] * b[2]) + a[1] * b[3]) + a[2] * b[0])
+        z = f(f(f(a[3] * b[2] + a[0] * b[1]) - a[1] * b[0]) + a[2] * b[3])
+        return np.array([x, y, z, w], f)
+
+    pi = f(3.14159265358979323846)
+    init = from_axis((0, 0, 1), 0.0)
+    out = []
+    for r in range(3):
+        roll = f(-pi / 8 + (pi / 8 - -pi / 8) * (f(r) / f(2)))
+        q_roll = mul(from_axis((1, 0, 0), roll), init)
+        for p in range(3):
+            pitch = f(-pi / 8 + (pi / 8 - -pi / 8) * (f(p) / f(2)))
+            q_pitch = mul(from_axis((0, 1, 0), pitch), q_roll)
+            for y in range(5):
+                yaw = f(0 + (pi / 2 - 0) * (f(y) / f(4)))
+                out.append(mul(from_axis((0, 0, 1), yaw), q_pitch))
+    return np.array(out, f)
