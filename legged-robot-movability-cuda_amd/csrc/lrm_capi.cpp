@@ -381,7 +381,12 @@ int lrm_any_in_sphere_dev(const float* cx, const float* cy, const float* cz, siz
                           const float* ty, const float* tz, size_t nt, float radius, uint8_t* out, void* stream) {
     if (!out || (nc && (!cx || !cy || !cz)) || (nt && (!tx || !ty || !tz))) return fail(LRM_EINVAL, "null argument");
     if (nc == 0) return LRM_OK;
-    HIP_TRY(lrm_launch_any_in_shape(0, cx, cy, cz, nc, tx, ty, tz, nt, radius, 0.f, 0.f, out, (hipStream_t)stream),
+    float* boxes = nullptr;
+    if (nt >= 4096) {
+        const int rc = tile_boxes(nt, &boxes);
+        if (rc != LRM_OK) return rc;
+    }
+    HIP_TRY(lrm_launch_any_in_shape(0, cx, cy, cz, nc, tx, ty, tz, nt, radius, 0.f, 0.f, boxes, out, (hipStream_t)stream),
             "in_sphere launch");
     return LRM_OK;
 }
@@ -390,7 +395,12 @@ int lrm_any_in_cylinder_dev(const float* cx, const float* cy, const float* cz, s
                             uint8_t* out, void* stream) {
     if (!out || (nc && (!cx || !cy || !cz)) || (nt && (!tx || !ty || !tz))) return fail(LRM_EINVAL, "null argument");
     if (nc == 0) return LRM_OK;
-    HIP_TRY(lrm_launch_any_in_shape(1, cx, cy, cz, nc, tx, ty, tz, nt, radius, plus_z, minus_z, out,
+    float* boxes = nullptr;
+    if (nt >= 4096) {
+        const int rc = tile_boxes(nt, &boxes);
+        if (rc != LRM_OK) return rc;
+    }
+    HIP_TRY(lrm_launch_any_in_shape(1, cx, cy, cz, nc, tx, ty, tz, nt, radius, plus_z, minus_z, boxes, out,
                                     (hipStream_t)stream), "in_cylinder launch");
     return LRM_OK;
 }

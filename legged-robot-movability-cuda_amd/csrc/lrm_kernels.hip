@@ -570,14 +570,53 @@ template <int kShape>
 __global__ __launch_bounds__(kBlock) void any_in_shape_kernel(
     const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz, size_t nc,
     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, size_t nt,
-    float radius, float plus_z, float minus_z, uint8_t* __restrict__ out) {
+    float radius, float plus_z, float minus_z, const float* __restrict__ boxes, uint8_t* __restrict__ out) {
     __shared__ float s_tx[kTargetTile], s_ty[kTargetTile], s_tz[kTargetTile];
+    __shared__ float s_red[6][kBlock / 64];
+    __shared__ float s_cbox[6];
     // one centre per thread, the whole block sweeps the same LDS tile (broadcast reads)
     const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = c < nc;
     const float px = live ? cx[c] : 0.f, py = live ? cy[c] : 0.f, pz = live ? cz[c] : 0.f;
+    if (boxes) {
+        // bounding box of this block's centres: a target tile whose box is out of reach of that
+        // box cannot contain a hit for any of them (block-uniform skip)
+        float lo[3] = {live ? px : 3.0e38f, live ? py : 3.0e38f, live ? pz : 3.0e38f};
+        float hi[3] = {live ? px : -3.0e38f, live ? py : -3.0e38f, live ? pz : -3.0e38f};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+            }
+        if ((threadIdx.x & 63) == 0)
+            for (int a = 0; a < 3; a++) {
+                s_red[a][threadIdx.x >> 6] = lo[a];
+                s_red[3 + a][threadIdx.x >> 6] = hi[a];
+            }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            float v = s_red[threadIdx.x][0];
+            for (int w = 1; w < kBlock / 64; w++) v = (threadIdx.x < 3) ? fminf(v, s_red[threadIdx.x][w]) : fmaxf(v, s_red[threadIdx.x][w]);
+            s_cbox[threadIdx.x] = v;
+        }
+        __syncthreads();
+    }
     bool found = false;
     for (size_t t0 = 0; t0 < nt; t0 += kTargetTile) {
+        if (boxes) { // block-uniform
+            const float* bb = boxes + (t0 / kTargetTile) * 6;
+            const float gx = fmaxf(fmaxf(bb[0] - s_cbox[3], s_cbox[0] - bb[3]), 0.f); // gaps between the two boxes
+            const float gy = fmaxf(fmaxf(bb[1] - s_cbox[4], s_cbox[1] - bb[4]), 0.f);
+            const float gz = fmaxf(fmaxf(bb[2] - s_cbox[5], s_cbox[2] - bb[5]), 0.f);
+            const float slack = 0.999f; // the gaps are lower bounds; keep a margin for their rounding
+            bool skip;
+            if (kShape == 0) skip = (gx * gx + gy * gy + gz * gz) * slack >= radius * radius;
+            else // cylinder: radial gap, or the z windows (target.z - centre.z in (minus_z, plus_z)) cannot overlap
+                skip = (gx * gx + gy * gy) * slack >= radius * radius || (bb[2] - s_cbox[5]) >= plus_z + 1e-3f * fabsf(plus_z) + 1e-3f ||
+                       (bb[5] - s_cbox[2]) <= minus_z - 1e-3f * fabsf(minus_z) - 1e-3f;
+            if (skip) continue;
+        }
         const int tile_n = (int)((nt - t0 < (size_t)kTargetTile) ? (nt - t0) : (size_t)kTargetTile);
         __syncthreads();
         for (int i = threadIdx.x; i < tile_n; i += kBlock) {
@@ -709,14 +748,19 @@ hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* b
 
 hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, const float* cz, size_t nc,
                                    const float* tx, const float* ty, const float* tz, size_t nt, float radius,
-                                   float plus_z, float minus_z, uint8_t* out, hipStream_t st) {
+                                   float plus_z, float minus_z, float* tile_boxes, uint8_t* out, hipStream_t st) {
+    if (tile_boxes && nt) {
+        hipLaunchKernelGGL(tile_aabb_kernel, dim3((unsigned)((nt + 1023) / 1024)), dim3(kBlock), 0, st, tx, ty, tz, nt, tile_boxes);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     const dim3 grid((unsigned)((nc + kBlock - 1) / kBlock));
     if (shape == 0)
         hipLaunchKernelGGL(any_in_shape_kernel<0>, grid, dim3(kBlock), 0, st, cx, cy, cz, nc, tx, ty, tz, nt, radius,
-                           plus_z, minus_z, out);
+                           plus_z, minus_z, tile_boxes, out);
     else
         hipLaunchKernelGGL(any_in_shape_kernel<1>, grid, dim3(kBlock), 0, st, cx, cy, cz, nc, tx, ty, tz, nt, radius,
-                           plus_z, minus_z, out);
+                           plus_z, minus_z, tile_boxes, out);
     return hipGetLastError();
 }
 

@@ -186,3 +186,25 @@ def test_reach_any_on_terrain_raster_with_tile_culling(lrm, oracle, torch_cuda):
     assert np.array_equal(out.cpu().numpy(), want)
     assert np.array_equal(all_legs.cpu().numpy(), want.min(axis=0))
     assert 0.05 < want.mean() < 0.95
+
+
+def test_any_in_shape_with_tile_box_skipping(lrm, torch_cuda):
+    """Clouds of >= 4096 targets take the tile bounding-box skip in the sphere / cylinder
+    reductions: same answers as the plain float32 restatement (raster-ordered and shuffled clouds)."""
+    from lrm_amd import workloads
+    ground = workloads.terrain(96)  # 9216 points, raster order
+    centres = workloads.body_lattice(ground, 900, seed=5)
+    rng = np.random.default_rng(2)
+    for cloud in (ground, ground[rng.permutation(len(ground))]):
+        cx, cy, cz = soa(torch_cuda, centres)
+        tx, ty, tz = soa(torch_cuda, cloud)
+        for radius in (60.0, 400.0):
+            s = lrm.device.any_in_sphere(cx, cy, cz, tx, ty, tz, radius)
+            torch_cuda.cuda.synchronize()
+            assert np.array_equal(s.cpu().numpy().astype(bool), _any_in_sphere(centres, cloud, radius))
+        for (r, pz, mz) in ((181.0, 250.0, -110.0), (510.0, 120.0, -310.0)):
+            c = lrm.device.any_in_cylinder(cx, cy, cz, tx, ty, tz, r, pz, mz)
+            torch_cuda.cuda.synchronize()
+            want = _any_in_cylinder(centres, cloud, r, pz, mz)
+            assert np.array_equal(c.cpu().numpy().astype(bool), want)
+            assert 0 < want.mean() < 1
