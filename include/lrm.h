@@ -161,6 +161,12 @@ int lrm_positionability(const float* bodies_aos, size_t nb, const float* targets
                         const LrmLegDimensions* legs, size_t nlegs, const float* quats,
                         size_t nquat, int reference_culls, uint8_t* body_mask_out, float* ms);
 
+/* Morton (Z-curve) order of a host cloud: order_out[k] = index of the k-th point along the curve.
+ * The pair kernels (lrm_reach_any_dev, lrm_any_in_*_dev) skip whole 1024-target tiles by bounding
+ * box; feeding them clouds (and centres / bodies) in this order makes the boxes compact in any
+ * orientation.  Results do not depend on the order.  lrm_positionability does this itself. */
+int lrm_morton_order(const float* xyz_aos, size_t n, uint64_t* order_out);
+
 /* in_sphere / in_cylinder any-reductions: launch_optimized_mem_in_sphere /
  * launch_optimized_mem_in_cylinder (collision.cu:68-98, :148-168):
  * out[c] = 1 iff some target lies in the sphere / cylinder centred on centre c. */

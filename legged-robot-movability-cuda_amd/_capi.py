@@ -75,6 +75,7 @@ def load():
         "lrm_dist_aos_dev": [vp, sz, vp, vp, vp, vp, vp],
         "lrm_reach_any_dev": [vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp],
         "lrm_positionability": [vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, vp, vp],
+        "lrm_morton_order": [vp, sz, vp],
         "lrm_dbg_fast_host": [vp, sz, vp, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
         "lrm_dbg_exact_math_dev": [vp, vp, sz, vp, vp, vp, vp],
@@ -213,6 +214,14 @@ def apply_dist_cpu(xyz, leg, quat=None):
     check(load().lrm_dist_cpu(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(d), _ptr(v),
                               C.addressof(ms)))
     return d, v, ms.value
+
+
+def morton_order(points):
+    """Indices that put an (n,3) cloud in Morton order (compact tiles for the pair kernels)."""
+    points = _f32(points, (-1, 3))
+    out = np.zeros(len(points), np.uint64)
+    check(load().lrm_morton_order(_ptr(points), len(points), _ptr(out)))
+    return out.astype(np.int64)
 
 
 class OctreeSettings(C.Structure):

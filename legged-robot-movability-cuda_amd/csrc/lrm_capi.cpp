@@ -4,7 +4,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 #include "lrm_compile.h"
 #include "lrm_launch.h"
@@ -89,6 +91,49 @@ int host_apply(int op, const float* xyz, size_t n, const LrmLegDimensions* leg, 
     return LRM_OK;
 }
 
+} // namespace
+
+namespace {
+// Morton (Z-curve) order of an AoS cloud: indices sorted by the interleaved 10-bit cell
+// coordinates of the bounding box.  Consecutive points are then spatially compact in ANY
+// orientation, which is what the tile bounding-box skipping of the pair kernels needs (a raster
+// row stops being a thin box as soon as the cloud is yawed).  "Any target" / per-body results do
+// not depend on the order, so sorting changes no output.
+std::vector<size_t> morton_order(const float* aos, const std::vector<size_t>& idx) {
+    const size_t n = idx.size();
+    std::vector<size_t> order(idx);
+    if (n < 2) return order;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (size_t i : idx)
+        for (int a = 0; a < 3; a++) {
+            const float v = aos[3 * i + a];
+            if (v < lo[a]) lo[a] = v;
+            if (v > hi[a]) hi[a] = v;
+        }
+    auto spread = [](uint32_t v) { // 10 bits -> every third bit
+        v &= 0x3ffu;
+        v = (v | (v << 16)) & 0x030000ffu;
+        v = (v | (v << 8)) & 0x0300f00fu;
+        v = (v | (v << 4)) & 0x030c30c3u;
+        v = (v | (v << 2)) & 0x09249249u;
+        return v;
+    };
+    std::vector<std::pair<uint32_t, size_t>> keyed(n);
+    for (size_t k = 0; k < n; k++) {
+        uint32_t key = 0;
+        for (int a = 0; a < 3; a++) {
+            const float span = hi[a] - lo[a];
+            float t = span > 0.f ? (aos[3 * idx[k] + a] - lo[a]) / span : 0.f;
+            if (!(t >= 0.f)) t = 0.f; // nan / below
+            if (t > 1.f) t = 1.f;
+            key |= spread((uint32_t)(t * 1023.f)) << a;
+        }
+        keyed[k] = {key, idx[k]};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    for (size_t k = 0; k < n; k++) order[k] = keyed[k].second;
+    return order;
+}
 } // namespace
 
 extern "C" {
@@ -405,6 +450,16 @@ int lrm_any_in_cylinder_dev(const float* cx, const float* cy, const float* cz, s
     return LRM_OK;
 }
 
+// Morton order of a host cloud (see morton_order above): order_out[k] = index of the k-th point.
+int lrm_morton_order(const float* xyz_aos, size_t n, uint64_t* order_out) {
+    if (n && (!xyz_aos || !order_out)) return fail(LRM_EINVAL, "null argument");
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = i;
+    const std::vector<size_t> o = morton_order(xyz_aos, idx);
+    for (size_t i = 0; i < n; i++) order_out[i] = (uint64_t)o[i];
+    return LRM_OK;
+}
+
 // ---- diagnostics: lrm_exact_math.h on arrays (host build / device build) -------------------
 int lrm_dbg_exact_math_host(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs) {
     if (n && (!a || !b || !at2 || !sn || !cs)) return fail(LRM_EINVAL, "null argument");
@@ -503,9 +558,15 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
         }
         return hipMemcpy(dst, stage.data(), 3 * pad * sizeof(float), hipMemcpyHostToDevice);
     };
-    HIP_TRY(upload(bodies, nullptr, nb, pb, d_b0.p), "hipMemcpy bodies");
+    // both clouds go to the device in Morton order (body_order maps device slot -> caller index)
+    std::vector<size_t> ident_b(nb), ident_t(nt);
+    for (size_t i = 0; i < nb; i++) ident_b[i] = i;
+    for (size_t i = 0; i < nt; i++) ident_t[i] = i;
+    const std::vector<size_t> body_order = morton_order(bodies, ident_b);
+    const std::vector<size_t> target_order = morton_order(targets, ident_t);
+    HIP_TRY(upload(bodies, body_order.data(), nb, pb, d_b0.p), "hipMemcpy bodies");
     size_t mt = nt; // targets kept after the one-time cull
-    if (nt) HIP_TRY(upload(targets, nullptr, nt, pt, d_t0.p), "hipMemcpy targets");
+    if (nt) HIP_TRY(upload(targets, target_order.data(), nt, pt, d_t0.p), "hipMemcpy targets");
     float* B0 = d_b0.as<float>();
     float* T0 = d_t0.as<float>();
     float* B = d_b.as<float>();
@@ -525,10 +586,10 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
         float e = 0.f;
         HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
         total_ms += e;
-        std::vector<size_t> alive;
+        std::vector<size_t> alive; // caller indices, in device (Morton) order
         for (size_t i = 0; i < nb; i++) {
             active[i] = (h1[i] == 0 && h2[i] != 0) ? 1 : 0;
-            if (active[i]) alive.push_back(i);
+            if (active[i]) alive.push_back(body_order[i]);
         }
         // eliminateFarTarget: keep the targets with a surviving body within 400 (compacted once, on the host)
         mt = 0;
@@ -542,9 +603,9 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
             HIP_TRY(hipMemcpy(h1.data(), d_m1.p, nt, hipMemcpyDeviceToHost), "hipMemcpy mask");
             HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
             total_ms += e;
-            std::vector<size_t> kept;
+            std::vector<size_t> kept; // caller indices, still in Morton order
             for (size_t i = 0; i < nt; i++)
-                if (h1[i]) kept.push_back(i);
+                if (h1[i]) kept.push_back(target_order[i]);
             mt = kept.size();
             if (mt) HIP_TRY(upload(targets, kept.data(), mt, pt, d_t0.p), "hipMemcpy targets");
         }
@@ -588,7 +649,8 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
                                         d_active.as<uint8_t>(), d_accepted.as<uint8_t>(), nullptr), "sweep update");
     }
     HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
-    HIP_TRY(hipMemcpy(body_mask_out, d_accepted.p, nb, hipMemcpyDeviceToHost), "hipMemcpy result");
+    HIP_TRY(hipMemcpy(h2.data(), d_accepted.p, nb, hipMemcpyDeviceToHost), "hipMemcpy result");
+    for (size_t i = 0; i < nb; i++) body_mask_out[body_order[i]] = h2[i];
     float e = 0.f;
     HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
     total_ms += e;

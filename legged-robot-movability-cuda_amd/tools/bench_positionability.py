@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", type=int, default=0, help="verify this many random bodies against the oracle")
     ap.add_argument("--mode", choices=["strict", "fast"], default="fast")
+    ap.add_argument("--morton", action="store_true", help="feed both clouds in Morton order (lrm_morton_order)")
     ap.add_argument("--sweep", action="store_true",
                     help="also time the whole robot_full_struct pipeline: 45 orientations + the reference culls")
     args = ap.parse_args()
@@ -31,6 +32,9 @@ def main():
     lrm_amd.set_mode(lrm_amd.MODE_FAST if args.mode == "fast" else lrm_amd.MODE_STRICT)
     ground = workloads.terrain(args.terrain_side)
     bodies = workloads.body_lattice(ground, args.bodies)
+    if args.morton:
+        ground = ground[lrm_amd.morton_order(ground)]
+        bodies = bodies[lrm_amd.morton_order(bodies)]
     legs = workloads.hexapod(lrm_amd.get_M2_leg, args.legs)
     tb = torch.from_numpy(np.ascontiguousarray(bodies.T)).cuda()
     tt = torch.from_numpy(np.ascontiguousarray(ground.T)).cuda()
@@ -48,7 +52,7 @@ def main():
     ms = a.elapsed_time(b) / args.reps
     pairs = float(len(bodies)) * len(ground) * len(legs)
     res = {"workload": f"config 3: {len(bodies)} body poses x {len(ground)} terrain points x {len(legs)} legs",
-           "mode": args.mode, "ms": ms, "leg_target_pairs_answered_per_s": pairs / (ms * 1e-3),
+           "mode": args.mode, "morton_order": bool(args.morton), "ms": ms, "leg_target_pairs_answered_per_s": pairs / (ms * 1e-3),
            "positionable_fraction": float(alll.float().mean().item()),
            "per_leg_fraction": out.float().mean(dim=1).cpu().tolist()}
     if args.check:
