@@ -336,14 +336,14 @@ int lrm_dist_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, co
 
 // ---- body x target aggregation ---------------------------------------------------------
 namespace {
-// Library-owned scratch for the tile bounding boxes of lrm_reach_any_dev (6 floats per 1024
-// targets), grown on demand: the first call for a larger cloud allocates (not capturable in a
+// Library-owned scratch for the bounding boxes of the pair kernels (6 floats per 1024-target tile
+// and per 64-target chunk), grown on demand: the first call for a larger cloud allocates (not capturable in a
 // graph); later calls only launch.
 float* g_boxes = nullptr;
 size_t g_boxes_cap = 0; // tiles
 int g_boxes_dev = -1;
 int tile_boxes(size_t nt, float** out) {
-    const size_t ntiles = (nt + 1023) / 1024;
+    const size_t ntiles = (nt + 1023) / 1024 * 17; // one box per tile + 16 chunk boxes per tile
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
     if (ntiles > g_boxes_cap || dev != g_boxes_dev) {

@@ -362,40 +362,55 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Axis-aligned bounding box of every 1024-target tile (one block per tile): lets reach_any_kernel
-// skip, per group of four bodies, the tiles no body can reach.  Pays off when the cloud has
-// spatial locality in memory order (terrain rasters, Morton-sorted scans); costs one pass otherwise.
+// Two levels of axis-aligned bounding boxes over the target cloud in memory order: one per
+// 1024-target tile (boxes[t*6..]) and one per 64-target chunk (boxes[(ntiles + c)*6..]); one block
+// per tile.  reach_any_kernel / any_in_shape_kernel skip, per group of bodies, the tiles and then
+// the chunks that are out of reach.  Pays off when the cloud has spatial locality in memory order
+// (Morton-sorted clouds: lrm_morton_order; terrain rasters); costs one cheap pass otherwise.
 __global__ __launch_bounds__(kBlock) void tile_aabb_kernel(const float* __restrict__ tx, const float* __restrict__ ty,
-                                                           const float* __restrict__ tz, size_t nt,
-                                                           float* __restrict__ boxes /* [ntiles][6] */) {
-    __shared__ float s_red[6][kBlock / 64];
+                                                           const float* __restrict__ tz, size_t nt, size_t ntiles,
+                                                           float* __restrict__ boxes) {
+    __shared__ float s_red[6][16];
     const size_t t0 = (size_t)blockIdx.x * 1024;
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (size_t i = t0 + threadIdx.x; i < t0 + 1024 && i < nt; i += kBlock) {
-        const float v[3] = {tx[i], ty[i], tz[i]};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int sub = wave; sub < 16; sub += kBlock / 64) { // each wave: four 64-target chunks
+        const size_t i = t0 + (size_t)sub * 64 + lane;
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        if (i < nt) {
+            lo[0] = hi[0] = tx[i];
+            lo[1] = hi[1] = ty[i];
+            lo[2] = hi[2] = tz[i];
+        }
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            lo[a] = fminf(lo[a], v[a]);
-            hi[a] = fmaxf(hi[a], v[a]);
+        for (int a = 0; a < 3; a++)
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+            }
+        if (lane == 0) {
+            const size_t c = (size_t)blockIdx.x * 16 + sub;
+            for (int a = 0; a < 3; a++) {
+                s_red[a][sub] = lo[a];
+                s_red[3 + a][sub] = hi[a];
+                boxes[(ntiles + c) * 6 + a] = lo[a];     // an empty chunk keeps (+big, -big): never "near"
+                boxes[(ntiles + c) * 6 + 3 + a] = hi[a];
+            }
         }
     }
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-        for (int off = 32; off > 0; off >>= 1) {
-            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
-            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
-        }
-    if ((threadIdx.x & 63) == 0)
-        for (int a = 0; a < 3; a++) {
-            s_red[a][threadIdx.x >> 6] = lo[a];
-            s_red[3 + a][threadIdx.x >> 6] = hi[a];
-        }
     __syncthreads();
     if (threadIdx.x < 6) {
         float v = s_red[threadIdx.x][0];
-        for (int w = 1; w < kBlock / 64; w++) v = (threadIdx.x < 3) ? fminf(v, s_red[threadIdx.x][w]) : fmaxf(v, s_red[threadIdx.x][w]);
+        for (int w = 1; w < 16; w++) v = (threadIdx.x < 3) ? fminf(v, s_red[threadIdx.x][w]) : fmaxf(v, s_red[threadIdx.x][w]);
         boxes[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
     }
+}
+
+// squared distance from a point to a box (lower bound of the distance to every member)
+__device__ __forceinline__ float box_dist2(const float* bb, float x, float y, float z) {
+    const float ex = fmaxf(fmaxf(bb[0] - x, x - bb[3]), 0.f);
+    const float ey = fmaxf(fmaxf(bb[1] - y, y - bb[4]), 0.f);
+    const float ez = fmaxf(fmaxf(bb[2] - z, z - bb[5]), 0.f);
+    return ex * ex + ey * ey + ez * ez;
 }
 
 template <bool kFast>
@@ -454,13 +469,9 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
               bool mine = false;
               const size_t tl = tw0 + lane;
               if (tl < ntiles && found != all_found) {
-                  const float* bb = boxes + tl * 6;
-                  const float ex = fmaxf(fmaxf(bb[0] - body.x, body.x - bb[3]), 0.f);
-                  const float ey = fmaxf(fmaxf(bb[1] - body.y, body.y - bb[4]), 0.f);
-                  const float ez = fmaxf(fmaxf(bb[2] - body.z, body.z - bb[5]), 0.f);
                   // box distance is a lower bound of every member's distance; 1e-3 relative slack
                   // for the rounding of the bound itself
-                  mine = (ex * ex + ey * ey + ez * ez) * 0.999f <= r2max;
+                  mine = box_dist2(boxes + tl * 6, body.x, body.y, body.z) * 0.999f <= r2max;
               }
               const unsigned long long mm = __ballot(mine);
               if (lane == 0 && mm) {
@@ -485,6 +496,8 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
             __syncthreads();
             if (found != all_found) { // wave-uniform
                 for (int s = 0; s < tile_n; s += 64) {
+                    // second level: the 64-target chunk's own box (wave-uniform skip)
+                    if (boxes && box_dist2(boxes + (ntiles + (t0 + s) / 64) * 6, body.x, body.y, body.z) * 0.999f > r2max) continue;
                     const int i = s + lane;
                     bool keep = false;
                     LrmVec3 t{0.f, 0.f, 0.f};
@@ -603,6 +616,7 @@ __global__ __launch_bounds__(kBlock) void any_in_shape_kernel(
         __syncthreads();
     }
     bool found = false;
+    const size_t ntiles = (nt + kTargetTile - 1) / kTargetTile;
     for (size_t t0 = 0; t0 < nt; t0 += kTargetTile) {
         if (boxes) { // block-uniform
             const float* bb = boxes + (t0 / kTargetTile) * 6;
@@ -627,6 +641,19 @@ __global__ __launch_bounds__(kBlock) void any_in_shape_kernel(
         __syncthreads();
         if (live && !found) {
             for (int i = 0; i < tile_n; i++) {
+                if (boxes && (i & 63) == 0) { // second level: skip a 64-target chunk out of this centre's reach
+                    const float* cb = boxes + (ntiles + (t0 + i) / 64) * 6;
+                    const float gx = fmaxf(fmaxf(cb[0] - px, px - cb[3]), 0.f), gy = fmaxf(fmaxf(cb[1] - py, py - cb[4]), 0.f);
+                    bool far;
+                    if (kShape == 0) {
+                        const float gz = fmaxf(fmaxf(cb[2] - pz, pz - cb[5]), 0.f);
+                        far = (gx * gx + gy * gy + gz * gz) * 0.999f >= radius * radius;
+                    } else {
+                        far = (gx * gx + gy * gy) * 0.999f >= radius * radius || (cb[2] - pz) >= plus_z + 1e-3f * fabsf(plus_z) + 1e-3f ||
+                              (cb[5] - pz) <= minus_z - 1e-3f * fabsf(minus_z) - 1e-3f;
+                    }
+                    if (far) { i += 63; continue; }
+                }
                 bool in;
                 if (kShape == 0) {
                     const float ax = px - s_tx[i], ay = py - s_ty[i], az = pz - s_tz[i];
@@ -734,7 +761,7 @@ hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* b
                                 int nlegs, float* tile_boxes, const uint8_t* body_active, uint8_t* out_leg_body,
                                 uint8_t* all_legs_out, bool fast, hipStream_t st) {
     if (tile_boxes && nt) {
-        hipLaunchKernelGGL(tile_aabb_kernel, dim3((unsigned)((nt + 1023) / 1024)), dim3(kBlock), 0, st, tx, ty, tz, nt, tile_boxes);
+        hipLaunchKernelGGL(tile_aabb_kernel, dim3((unsigned)((nt + 1023) / 1024)), dim3(kBlock), 0, st, tx, ty, tz, nt, (nt + 1023) / 1024, tile_boxes);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -750,7 +777,7 @@ hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, 
                                    const float* tx, const float* ty, const float* tz, size_t nt, float radius,
                                    float plus_z, float minus_z, float* tile_boxes, uint8_t* out, hipStream_t st) {
     if (tile_boxes && nt) {
-        hipLaunchKernelGGL(tile_aabb_kernel, dim3((unsigned)((nt + 1023) / 1024)), dim3(kBlock), 0, st, tx, ty, tz, nt, tile_boxes);
+        hipLaunchKernelGGL(tile_aabb_kernel, dim3((unsigned)((nt + 1023) / 1024)), dim3(kBlock), 0, st, tx, ty, tz, nt, (nt + 1023) / 1024, tile_boxes);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
