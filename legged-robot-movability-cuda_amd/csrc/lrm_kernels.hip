@@ -424,6 +424,7 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
     __shared__ LrmCompiledLeg::LeanCircle s_lean[LRM_MAX_LEGS][16];
     __shared__ int s_todo;
     __shared__ unsigned s_near[2];
+    __shared__ float s_chunk_box[16 * 6]; // boxes of the 16 chunks of the tile in LDS
 
     for (int i = threadIdx.x; i < nlegs * 64; i += kBlock)
         reinterpret_cast<float*>(&s_lean[i >> 6][0])[i & 63] = reinterpret_cast<const float*>(&legs[i >> 6].lean[0][0])[i & 63];
@@ -493,11 +494,12 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
                 s_ty[i] = ty[t0 + i];
                 s_tz[i] = tz[t0 + i];
             }
+            if (boxes && threadIdx.x < 96) s_chunk_box[threadIdx.x] = boxes[(ntiles + t0 / 64) * 6 + threadIdx.x];
             __syncthreads();
             if (found != all_found) { // wave-uniform
                 for (int s = 0; s < tile_n; s += 64) {
                     // second level: the 64-target chunk's own box (wave-uniform skip)
-                    if (boxes && box_dist2(boxes + (ntiles + (t0 + s) / 64) * 6, body.x, body.y, body.z) * 0.999f > r2max) continue;
+                    if (boxes && box_dist2(s_chunk_box + (s >> 6) * 6, body.x, body.y, body.z) * 0.999f > r2max) continue;
                     const int i = s + lane;
                     bool keep = false;
                     LrmVec3 t{0.f, 0.f, 0.f};
@@ -587,6 +589,7 @@ __global__ __launch_bounds__(kBlock) void any_in_shape_kernel(
     __shared__ float s_tx[kTargetTile], s_ty[kTargetTile], s_tz[kTargetTile];
     __shared__ float s_red[6][kBlock / 64];
     __shared__ float s_cbox[6];
+    __shared__ float s_chunk_box[16 * 6];
     // one centre per thread, the whole block sweeps the same LDS tile (broadcast reads)
     const size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = c < nc;
@@ -638,11 +641,12 @@ __global__ __launch_bounds__(kBlock) void any_in_shape_kernel(
             s_ty[i] = ty[t0 + i];
             s_tz[i] = tz[t0 + i];
         }
+        if (boxes && threadIdx.x < 96) s_chunk_box[threadIdx.x] = boxes[(ntiles + t0 / 64) * 6 + threadIdx.x];
         __syncthreads();
         if (live && !found) {
             for (int i = 0; i < tile_n; i++) {
                 if (boxes && (i & 63) == 0) { // second level: skip a 64-target chunk out of this centre's reach
-                    const float* cb = boxes + (ntiles + (t0 + i) / 64) * 6;
+                    const float* cb = s_chunk_box + (i >> 6) * 6;
                     const float gx = fmaxf(fmaxf(cb[0] - px, px - cb[3]), 0.f), gy = fmaxf(fmaxf(cb[1] - py, py - cb[4]), 0.f);
                     bool far;
                     if (kShape == 0) {
