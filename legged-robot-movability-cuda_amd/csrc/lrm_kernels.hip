@@ -424,7 +424,6 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
     __shared__ LrmCompiledLeg::LeanCircle s_lean[LRM_MAX_LEGS][16];
     __shared__ int s_todo;
     __shared__ unsigned s_near[2];
-    __shared__ float s_chunk_box[16 * 6]; // boxes of the 16 chunks of the tile in LDS
 
     for (int i = threadIdx.x; i < nlegs * 64; i += kBlock)
         reinterpret_cast<float*>(&s_lean[i >> 6][0])[i & 63] = reinterpret_cast<const float*>(&legs[i >> 6].lean[0][0])[i & 63];
@@ -494,12 +493,11 @@ __global__ __launch_bounds__(kBlock) void reach_any_kernel(
                 s_ty[i] = ty[t0 + i];
                 s_tz[i] = tz[t0 + i];
             }
-            if (boxes && threadIdx.x < 96) s_chunk_box[threadIdx.x] = boxes[(ntiles + t0 / 64) * 6 + threadIdx.x];
             __syncthreads();
             if (found != all_found) { // wave-uniform
                 for (int s = 0; s < tile_n; s += 64) {
-                    // second level: the 64-target chunk's own box (wave-uniform skip)
-                    if (boxes && box_dist2(s_chunk_box + (s >> 6) * 6, body.x, body.y, body.z) * 0.999f > r2max) continue;
+                    // (the chunk-level boxes are not used here: against a 0.5 m reach sphere they skip too
+                    // little to pay for their test; the sphere / cylinder reductions do use them)
                     const int i = s + lane;
                     bool keep = false;
                     LrmVec3 t{0.f, 0.f, 0.f};
