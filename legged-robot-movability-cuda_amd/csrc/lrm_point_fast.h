@@ -334,8 +334,15 @@ LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmDistTables T
     LrmVec3 b = a;
     const float ang = lrm_atan2f(a.y, a.x);
     const float ang_flip = (ang > 0) ? ang - LRM_PI_F : ang + LRM_PI_F;
-    const bool res = lrm_finish_closest_fast(L, T, a, ang, unc);
-    const bool resflip = lrm_finish_closest_fast(L, T, b, ang_flip, unc);
+    // one copy of the candidate evaluation, executed twice (halves the code the wave walks through)
+    bool res = false, resflip = false;
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        LrmVec3 p = k ? b : a;
+        const bool r_k = lrm_finish_closest_fast(L, T, p, k ? ang_flip : ang, unc);
+        if (k) { b = p; resflip = r_k; }
+        else { a = p; res = r_k; }
+    }
     // The two candidates are often the same configuration up to rounding (yaw within 30 deg of
     // the axis: one of them is "mega-saturated" onto the other): the strict comparison of the
     // strict norms is the only way to pick the same one.
