@@ -13,12 +13,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "lrm_launch.h"
+#include "lrm_types.h"
+#define LRM_FRESH(L) lrm_fresh(L)
 #include "lrm_point.h"
 #include "lrm_point_fast.h"
 
 namespace {
 
 constexpr int kBlock = 256;
+// The kernels below take the compiled leg BY VALUE (it travels in the kernarg segment, no device
+// allocation, graph-capturable) but read it through lrm_kernarg<>(offset) rather than through the
+// parameter: the parameter's loads are hoisted to the top of the kernel, overflow the SGPR file
+// (98 SGPR spills, ~150 v_readlane per point in the fused kernel), and its address cannot be
+// taken without a 2.7 KB/lane scratch copy.  Offsets follow the kernarg layout (natural
+// alignment): x, y, z, n -> 32;  xyz, n -> 16.
+constexpr unsigned kLegArgSoA = 32, kLegArgAoS = 16;
+static_assert(alignof(LrmCompiledLeg) == 16 && sizeof(void*) == 8 && sizeof(size_t) == 8, "kernarg layout");
 #ifndef LRM_DIST_MIN_WAVES
 #define LRM_DIST_MIN_WAVES 4 // <= 128 VGPRs (4 waves/SIMD): measured 5 % faster than the unconstrained 141
 #endif
@@ -74,10 +84,11 @@ template <bool kBits, bool kFast>
 __global__ __launch_bounds__(kBlock, LRM_REACH_MIN_WAVES) void reach_soa_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ y,
                                                            const float* __restrict__ z, size_t n,
-                                                           const LrmCompiledLeg L,
+                                                           const LrmCompiledLeg L_kernarg,
                                                            uint8_t* __restrict__ mask,
                                                            uint64_t* __restrict__ bits) {
     __shared__ LdsTables s_tab;
+    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kLegArgSoA);
     stage_lists(L, &s_tab);
     const size_t nquad = n >> 2;
     // every wave runs the same number of iterations so that the shuffles below see all lanes
@@ -159,8 +170,9 @@ __global__ __launch_bounds__(kBlock, LRM_REACH_MIN_WAVES) void reach_soa_kernel(
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void reach_lean_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ z, size_t n,
-                                                            const LrmCompiledLeg L, uint8_t* __restrict__ mask) {
+                                                            const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask) {
     __shared__ LrmCompiledLeg::LeanCircle s_lean[16];
+    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kLegArgSoA);
     if (threadIdx.x < 64) reinterpret_cast<float*>(s_lean)[threadIdx.x] = reinterpret_cast<const float*>(&L.lean[0][0])[threadIdx.x];
     __syncthreads();
     const size_t nquad = n >> 2;
@@ -185,8 +197,9 @@ __global__ __launch_bounds__(kBlock) void reach_lean_kernel(const float* __restr
 template <bool kBits>
 __global__ __launch_bounds__(kBlock) void reach_fixup_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ z, size_t n,
-                                                             const LrmCompiledLeg L, uint8_t* __restrict__ mask,
+                                                             const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask,
                                                              uint64_t* __restrict__ bits) {
+    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kLegArgSoA);
     // One lane owns 16 consecutive points (one coalesced 16-byte mask load), four lanes one bit
     // word.  No LDS: the rare strict re-evaluation reads the circle lists from the kernel argument
     // segment directly.
@@ -243,10 +256,11 @@ template <bool kFast>
 __global__ __launch_bounds__(kBlock) void reach_soa_scalar_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ y,
                                                                   const float* __restrict__ z, size_t n,
-                                                                  const LrmCompiledLeg L,
+                                                                  const LrmCompiledLeg L_kernarg,
                                                                   uint8_t* __restrict__ mask,
                                                                   uint64_t* __restrict__ bits) {
     __shared__ LdsTables s_tab;
+    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kLegArgSoA);
     stage_lists(L, &s_tab);
     const size_t stride = (size_t)gridDim.x * kBlock;
     const size_t n_pad = (n + 63) & ~(size_t)63;
@@ -272,13 +286,14 @@ template <int kOp, bool kFast>
 __global__ __launch_bounds__(kBlock, LRM_DIST_MIN_WAVES) void dist_soa_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ y,
                                                           const float* __restrict__ z, size_t n,
-                                                          const LrmCompiledLeg L,
+                                                          const LrmCompiledLeg L_kernarg,
                                                           uint8_t* __restrict__ mask,
                                                           uint64_t* __restrict__ bits,
                                                           float* __restrict__ dx,
                                                           float* __restrict__ dy,
                                                           float* __restrict__ dz) {
     __shared__ LdsTables s_tab;
+    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kLegArgSoA);
     stage_lists(L, &s_tab);
     const size_t stride = (size_t)gridDim.x * kBlock;
     const size_t n_pad = (n + 63) & ~(size_t)63; // whole waves iterate together (ballot below)
@@ -304,9 +319,10 @@ __global__ __launch_bounds__(kBlock, LRM_DIST_MIN_WAVES) void dist_soa_kernel(co
 // AoS variants for the apply_kernel boundary (cross_compiled.cu:33-79)
 template <bool kFast>
 __global__ __launch_bounds__(kBlock) void reach_aos_kernel(const float* __restrict__ xyz, size_t n,
-                                                           const LrmCompiledLeg L,
+                                                           const LrmCompiledLeg L_kernarg,
                                                            uint8_t* __restrict__ mask) {
     __shared__ LdsTables s_tab;
+    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kLegArgAoS);
     stage_lists(L, &s_tab);
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -317,10 +333,11 @@ __global__ __launch_bounds__(kBlock) void reach_aos_kernel(const float* __restri
 
 template <int kOp, bool kFast>
 __global__ __launch_bounds__(kBlock) void dist_aos_kernel(const float* __restrict__ xyz, size_t n,
-                                                          const LrmCompiledLeg L,
+                                                          const LrmCompiledLeg L_kernarg,
                                                           uint8_t* __restrict__ mask,
                                                           float* __restrict__ dxyz) {
     __shared__ LdsTables s_tab;
+    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kLegArgAoS);
     stage_lists(L, &s_tab);
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {

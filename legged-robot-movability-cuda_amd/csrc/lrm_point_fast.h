@@ -48,6 +48,12 @@
 #define LRM_BAND 4.0e-6f
 #endif
 
+// Device kernels that read the leg from the kernarg segment define LRM_FRESH as lrm_fresh: the
+// constants are then re-fetched (s_load) per phase instead of staying live in SGPRs throughout.
+#ifndef LRM_FRESH
+#define LRM_FRESH(L) (L)
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LRM_FAST_SQRT(v) __builtin_amdgcn_sqrtf(v)
 #define LRM_FAST_RSQ(v) __builtin_amdgcn_rsqf(v)
@@ -339,7 +345,7 @@ LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmDistTables T
 #pragma unroll 1
     for (int k = 0; k < 2; k++) {
         LrmVec3 p = k ? b : a;
-        const bool r_k = lrm_finish_closest_fast(L, T, p, k ? ang_flip : ang, unc);
+        const bool r_k = lrm_finish_closest_fast(LRM_FRESH(L), T, p, k ? ang_flip : ang, unc);
         if (k) { b = p; resflip = r_k; }
         else { a = p; res = r_k; }
     }
@@ -348,9 +354,10 @@ LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmDistTables T
     // strict norms is the only way to pick the same one.
     const bool use_direct = (res == resflip) ? (lrm_norm3(a) < lrm_norm3(b)) : res;
     r = use_direct ? a : b;
-    buffer = r.x * L.sin_pitch_rev;
-    r.x = r.x * L.cos_pitch_rev - r.z * L.sin_pitch_rev;
-    r.z = buffer + r.z * L.cos_pitch_rev;
+    const LrmCompiledLeg& Le = LRM_FRESH(L);
+    buffer = r.x * Le.sin_pitch_rev;
+    r.x = r.x * Le.cos_pitch_rev - r.z * Le.sin_pitch_rev;
+    r.z = buffer + r.z * Le.cos_pitch_rev;
     return res || resflip;
 }
 
@@ -360,10 +367,11 @@ LRM_HD bool lrm_dist_global_fast(const LrmCompiledLeg& L, const LrmDistTables T,
     u.x = u.x * L.cos_body - u.y * L.sin_body;
     u.y = buffer + u.y * L.cos_body;
     const bool r = lrm_dist_circles_fast(L, T, u, unc);
-    buffer = u.x * -L.sin_body;
-    u.x = u.x * L.cos_body - u.y * -L.sin_body;
-    u.y = buffer + u.y * L.cos_body;
-    p = lrm_qrot(L.fwd_rot, u);
+    const LrmCompiledLeg& Le = LRM_FRESH(L);
+    buffer = u.x * -Le.sin_body;
+    u.x = u.x * Le.cos_body - u.y * -Le.sin_body;
+    u.y = buffer + u.y * Le.cos_body;
+    p = lrm_qrot(Le.fwd_rot, u);
     return r;
 }
 

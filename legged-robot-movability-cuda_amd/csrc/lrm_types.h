@@ -10,6 +10,33 @@
 #define LRM_HD inline
 #endif
 
+// lrm_fresh(v): the same object through a pointer the optimiser cannot see through.  Used on the
+// by-value kernel argument (kernarg segment, constant address space): loads through the result
+// are re-issued as s_load at the point of use (the scalar cache holds the segment) instead of
+// being hoisted to the top of the kernel, where ~100 live constants overflow the SGPR file and
+// come back as v_readlane spills in the hot loop.  `v` MUST live in constant/global memory.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+__device__ __forceinline__ const T& lrm_fresh(const T& v) {
+    const __attribute__((address_space(4))) T* p = (const __attribute__((address_space(4))) T*)&v;
+    asm volatile("" : "+s"(p));
+    return *(const T*)p;
+}
+template <class T>
+__device__ __forceinline__ const T& lrm_kernarg(unsigned offset) {
+    const __attribute__((address_space(4))) char* p =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(const T*)(p + offset);
+}
+#else
+template <class T>
+LRM_HD const T& lrm_fresh(const T& v) { return v; }
+template <class T>
+LRM_HD const T& lrm_kernarg(unsigned) { // device only: this is what the host pass of a kernel body sees, never run
+    return *reinterpret_cast<const T*>(sizeof(T));
+}
+#endif
+
 #define LRM_N_CIRCLES 4  // circles.cu.h:8-14 MAX_CIRCLES
 #define LRM_N_CORNERS 10 // circles.cu.h:15 MAX_INTERSECT
 
