@@ -215,6 +215,10 @@ const char* lrm_octree_last_error(void);
 int lrm_dbg_exact_math_host(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs);
 int lrm_dbg_exact_math_dev(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs,
                            void* stream);
+/* The device's correctly rounded square root (csrc/lrm_exact_math.h, lrm_sqrtf) against the
+ * compiler's IEEE sqrtf on ALL 2^32 float bit patterns: writes the number of patterns whose results
+ * differ bitwise (nan payloads included) and the first such pattern.  Synchronous. */
+int lrm_dbg_sqrt_check_dev(uint64_t* mismatches_out, uint32_t* first_bad_out);
 
 /* The filtered (LRM_MODE_FAST) per-point evaluation run on the host WITHOUT its strict
  * fallback, plus the per-point "uncertain" flags that would trigger the fallback.  Any output

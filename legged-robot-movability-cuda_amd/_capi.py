@@ -79,6 +79,7 @@ def load():
         "lrm_dbg_fast_host": [vp, sz, vp, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
         "lrm_dbg_exact_math_dev": [vp, vp, sz, vp, vp, vp, vp],
+        "lrm_dbg_sqrt_check_dev": [vp, vp],
         "lrm_any_in_sphere_dev": [vp, vp, vp, sz, vp, vp, vp, sz, fp, vp, vp],
         "lrm_any_in_cylinder_dev": [vp, vp, vp, sz, vp, vp, vp, sz, fp, fp, fp, vp, vp],
     }
@@ -255,6 +256,14 @@ def apply_oct(footholds, leg, settings=None, capacity=None):
         if rc != 0:
             raise LrmError(f"liblrm error {rc}: {load().lrm_octree_last_error().decode()}")
         return out[: n_out.value].copy(), ms.value
+
+
+def dbg_sqrt_check_dev():
+    """lrm_sqrtf vs the compiler's IEEE sqrtf on all 2^32 bit patterns, on the device -> (mismatches, first_bad)."""
+    bad = C.c_uint64(0)
+    first = C.c_uint32(0)
+    check(load().lrm_dbg_sqrt_check_dev(C.byref(bad), C.byref(first)))
+    return int(bad.value), int(first.value)
 
 
 def dbg_fast_host(xyz, leg, quat=None):

@@ -477,6 +477,22 @@ int lrm_dbg_exact_math_dev(const float* a, const float* b, size_t n, float* at2,
     return LRM_OK;
 }
 
+int lrm_dbg_sqrt_check_dev(uint64_t* mismatches_out, uint32_t* first_bad_out) {
+    if (!mismatches_out || !first_bad_out) return fail(LRM_EINVAL, "null argument");
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(&d, 2 * sizeof(unsigned long long)), "hipMalloc");
+    const unsigned long long init[2] = {0ull, ~0ull};
+    hipError_t e = hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = lrm_launch_sqrt_check(d, nullptr);
+    unsigned long long out[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(out, d, sizeof(out), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIP_TRY(e, "sqrt check");
+    *mismatches_out = out[0];
+    *first_bad_out = out[0] ? (uint32_t)(out[1] - 1) : 0u;
+    return LRM_OK;
+}
+
 // The filtered evaluation (lrm_point_fast.h) on the host, WITHOUT the strict fallback, with its
 // `uncertain` flags: tests check that every point not flagged equals the strict result and
 // count how many are flagged.  Outputs may be NULL.

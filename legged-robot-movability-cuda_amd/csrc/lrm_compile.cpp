@@ -234,6 +234,20 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
         out->dir_cos[i] = (float)std::cos((double)dirs[i]);
         out->dir_sin[i] = (float)std::sin((double)dirs[i]);
     }
+    // region table of the filters: the boolean form of "atan2f(y, x) > C" (lrm_gt_from_t) evaluated
+    // for the 16 sign patterns of (t_mid, t_s0, t_s1, y)
+    out->region_lut = 0;
+    for (unsigned pat = 0; pat < 16; pat++) {
+        const bool ypos = !(pat & 8u);
+        auto gt = [&](unsigned bit, float c) {
+            const bool tp = !(pat & bit), c_nonneg = c >= 0.f;
+            return (tp && ypos) || (!c_nonneg && (tp || ypos));
+        };
+        const bool upper = gt(1u, out->region_mid);
+        const bool more = upper ? gt(4u, out->full_sat[1]) : gt(2u, out->full_sat[0]);
+        const unsigned reg = (upper ? 2u : 0u) + ((upper != more) ? 1u : 0u);
+        out->region_lut |= reg << (2 * pat);
+    }
     // The cross-product form of the coxa range test needs both limits well inside
     // (-pi/2, pi/2) (the yaw is measured on the point mirrored into x >= 0); the region
     // constants must be finite and away from +-pi.  Anything else: strict path.

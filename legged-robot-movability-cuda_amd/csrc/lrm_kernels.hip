@@ -703,6 +703,26 @@ __global__ __launch_bounds__(kBlock) void exact_math_kernel(const float* __restr
     }
 }
 
+// diagnostic: lrm_sqrtf against the compiler's IEEE sqrtf on every float bit pattern
+__global__ __launch_bounds__(kBlock) void sqrt_check_kernel(unsigned long long* __restrict__ counters) {
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t first = blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long bad = 0, first_bad = ~0ull;
+    // 2^32 patterns: every thread walks its residue class (stride divides 2^32)
+    for (uint64_t u = first; u < (1ull << 32); u += stride) {
+        const float x = lrm_u2f((uint32_t)u);
+        const uint32_t got = lrm_f2u(lrm_sqrtf(x)), want = lrm_f2u(sqrtf(x));
+        if (got != want) {
+            bad++;
+            if (u + 1 < first_bad) first_bad = u + 1;
+        }
+    }
+    if (bad) {
+        atomicAdd(&counters[0], bad);
+        atomicMin(&counters[1], first_bad);
+    }
+}
+
 inline int grid_for(size_t work_items) {
     // memory-streaming launches: enough workgroups to fill 256 CUs x 8, grid-stride the rest
     size_t g = (work_items + kBlock - 1) / kBlock;
@@ -807,6 +827,11 @@ hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, 
     else
         hipLaunchKernelGGL(any_in_shape_kernel<1>, grid, dim3(kBlock), 0, st, cx, cy, cz, nc, tx, ty, tz, nt, radius,
                            plus_z, minus_z, tile_boxes, out);
+    return hipGetLastError();
+}
+
+hipError_t lrm_launch_sqrt_check(unsigned long long* counters_dev, hipStream_t st) {
+    hipLaunchKernelGGL(sqrt_check_kernel, dim3(2048), dim3(kBlock), 0, st, counters_dev);
     return hipGetLastError();
 }
 

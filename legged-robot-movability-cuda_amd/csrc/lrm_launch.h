@@ -23,6 +23,8 @@ hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, 
                                    const float* tx, const float* ty, const float* tz, size_t nt, float radius,
                                    float plus_z, float minus_z, float* tile_boxes /* workspace or null */, uint8_t* out,
                                    hipStream_t st);
+hipError_t lrm_launch_sqrt_check(unsigned long long* counters_dev /* [2]: mismatches, first bad pattern + 1 */,
+                                 hipStream_t st);
 hipError_t lrm_launch_exact_math(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs,
                                  hipStream_t st);
 hipError_t lrm_launch_rotate_soa(const float* sx, const float* sy, const float* sz, size_t n, const LrmCompiledLeg* rot_dev,

@@ -31,7 +31,7 @@ LRM_HD LrmVec3 lrm_qrot(const float* m, LrmVec3 v) {
 LRM_HD bool lrm_circle_valid(const LrmCircle c, float x, float y) {
     x -= c.x;
     y -= c.y;
-    const float mag = sqrtf(x * x + y * y);
+    const float mag = lrm_sqrtf(x * x + y * y);
     const float d = c.r - mag;
     const bool inside = !(lrm_f2u(d) >> 31);
     return (inside == (c.attract != 0.f)) || (fabsf(d) < LRM_MARGIN_F);
@@ -106,7 +106,7 @@ LRM_HD void lrm_clamp_on(float cx, float cy, float cr, bool attract, float& x, f
                          bool& valid) {
     x -= cx;
     y -= cy;
-    float mag = sqrtf(x * x + y * y);
+    float mag = lrm_sqrtf(x * x + y * y);
     d = cr - mag;
     const bool inside = !(lrm_f2u(d) >> 31);
     valid = (inside == attract) || (fabsf(d) < LRM_MARGIN_F);
@@ -158,7 +158,7 @@ LRM_HD bool lrm_plane_dist(const LrmCompiledLeg& L, const LrmCircle* lists, floa
     return overall;
 }
 
-LRM_HD float lrm_norm3(LrmVec3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+LRM_HD float lrm_norm3(LrmVec3 v) { return lrm_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
 
 // finish_finding_closest<bool>, one_leg.cu:215-278
 LRM_HD bool lrm_finish_closest(const LrmCompiledLeg& L, const LrmCircle* lists, LrmVec3& p,

@@ -71,11 +71,19 @@
 
 // "atan2f(y, x) > C" for a constant C in (-pi, pi) from the cross product t = cosC*y - sinC*x
 // (> 0: (x, y) is counter-clockwise of direction C by less than pi), with the wrap of atan2f at
-// +-pi handled, branch-free:   C >= 0: t > 0 and y >= 0;   C < 0: y >= 0 or t > 0.
+// +-pi handled:   C >= 0: t > 0 and y >= 0;   C < 0: y >= 0 or t > 0.
 // Doubt: |t| small (the point is near the ray), or x < 0 with y = +-0 (atan2f jumps from +pi to -pi).
-LRM_HD bool lrm_gt_from_t(float t, bool ypos, bool c_nonneg) {
-    const bool tp = t > 0.f;
-    return (tp & ypos) | ((!c_nonneg) & (tp | ypos));
+//
+// find_region (circles.cu.h:48-78) from the three cross products and y: the boolean form above
+// depends only on four signs (and on the signs of the three constants), so the host tabulates it (LrmCompiledLeg::region_lut, 2 bits per
+// sign pattern) and the per-point code gathers sign bits with shifts/and/or (full-rate VALU
+// operations on gfx950; a v_cmp + v_cndmask pair costs 4x as much).  t = +-0 reads as "positive"
+// or "negative" by its sign bit; every caller treats |t| <= band (> 0) as a doubt, so the
+// difference with `t > 0` never reaches a result.  Returns upper * 2 + fully_extended.
+LRM_HD uint32_t lrm_region_from_signs(uint32_t lut, float t_mid, float t_s0, float t_s1, float y) {
+    const uint32_t pat = (lrm_f2u(t_mid) >> 31) | ((lrm_f2u(t_s0) >> 30) & 2u) | ((lrm_f2u(t_s1) >> 29) & 4u) |
+                         ((lrm_f2u(y) >> 28) & 8u);
+    return (lut >> (pat << 1)) & 3u;
 }
 
 // (x, y, z): the point in the coxa frame (after place_over_coxa), approximate; `band` (mm) covers
@@ -96,15 +104,10 @@ LRM_HD bool lrm_reach_coxa_lean(const LrmCompiledLeg& L, const LrmCompiledLeg::L
     const float t_mid = __builtin_fmaf(L.dir_cos[0], z, -(L.dir_sin[0] * px));
     const float t_s0 = __builtin_fmaf(L.dir_cos[1], z, -(L.dir_sin[1] * px));
     const float t_s1 = __builtin_fmaf(L.dir_cos[2], z, -(L.dir_sin[2] * px));
-    const bool ypos = !(lrm_f2u(z) >> 31);
-    const bool upper = lrm_gt_from_t(t_mid, ypos, L.region_mid >= 0.f);
-    const bool more0 = lrm_gt_from_t(t_s0, ypos, L.full_sat[0] >= 0.f);
-    const bool more1 = lrm_gt_from_t(t_s1, ypos, L.full_sat[1] >= 0.f);
-    const bool more = (upper & more1) | ((!upper) & more0);
-    const bool fe = upper != more;
+    const uint32_t reg = lrm_region_from_signs(L.region_lut, t_mid, t_s0, t_s1, z);
     // doubt of the region: distance to any of the three rays, or to the atan2f wrap ray (x < 0, y = +-0)
     float macc = fminf(fminf(fabsf(t_mid), fabsf(t_s0)), fminf(fabsf(t_s1), fmaxf(px, fabsf(z))));
-    const LrmCompiledLeg::LeanCircle* c = lean + ((upper ? 8 : 0) + (fe ? 4 : 0));
+    const LrmCompiledLeg::LeanCircle* c = lean + reg * LRM_N_CIRCLES;
     float vacc = -3.0e38f;
 #pragma unroll
     for (int i = 0; i < LRM_N_CIRCLES; i++) {
@@ -176,12 +179,7 @@ LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, 
     const float t_mid = __builtin_fmaf(L.dir_cos[0], y, -(L.dir_sin[0] * x));
     const float t_s0 = __builtin_fmaf(L.dir_cos[1], y, -(L.dir_sin[1] * x));
     const float t_s1 = __builtin_fmaf(L.dir_cos[2], y, -(L.dir_sin[2] * x));
-    const bool ypos = !(lrm_f2u(y) >> 31);
-    const bool upper = lrm_gt_from_t(t_mid, ypos, L.region_mid >= 0.f);
-    const bool more0 = lrm_gt_from_t(t_s0, ypos, L.full_sat[0] >= 0.f);
-    const bool more1 = lrm_gt_from_t(t_s1, ypos, L.full_sat[1] >= 0.f);
-    const bool more = (upper & more1) | ((!upper) & more0);
-    const int reg = (upper ? 8 : 0) + ((upper != more) ? 4 : 0);
+    const int reg = (int)lrm_region_from_signs(L.region_lut, t_mid, t_s0, t_s1, y) * LRM_N_CIRCLES;
     float macc = fminf(fminf(fabsf(t_mid), fabsf(t_s0)), fminf(fabsf(t_s1), fmaxf(x, fabsf(y))));
     float maccq = 3.0e38f, magmin = 3.0e38f, vacc = -3.0e38f;
     const LrmCompiledLeg::DistCircle* dt = T.dist + reg;

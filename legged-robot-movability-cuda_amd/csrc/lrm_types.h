@@ -88,7 +88,9 @@ struct LrmCompiledLeg {
     int32_t n_ucorners;                 // corner points with exact duplicates removed
     float ucorner_x[LRM_N_CORNERS];
     float ucorner_y[LRM_N_CORNERS];
-    float pad_[1];
+    // find_region as a table: 2 bits (upper * 2 + fully_extended) per pattern of the sign bits of
+    // (t_mid, t_s0, t_s1, y) -- pattern bit k set = value k negative; see lrm_region_from_signs
+    uint32_t region_lut;
     // ---- lean reach filter (lrm_point_fast.h): everything below is decision-only data ----
     // body-frame point -> coxa frame in one affine map (row-major 3x4, FMA-evaluated):
     //   global: Rp * (Rz * (Rq * p) - (body,0,0));   pair: Rp * (Rz * t - (body,0,0)), t = target - body

@@ -148,6 +148,14 @@ def test_full_size_config2_1e7_points(lrm, oracle, torch_cuda):
     assert np.quantile(rn, 0.999) < 2e-2, np.quantile(rn, [0.5, 0.99, 0.999, 1.0])
 
 
+def test_device_sqrt_is_correctly_rounded_everywhere(lrm, torch_cuda):
+    """lrm_sqrtf (Goldschmidt/Markstein on v_rsq_f32 inside [2^-96, 2^96), the compiler's IEEE
+    expansion elsewhere) == IEEE sqrtf on every one of the 2^32 float bit patterns, on the device."""
+    from lrm_amd import _capi
+    bad, first = _capi.dbg_sqrt_check_dev()
+    assert bad == 0, f"{bad} patterns differ, first 0x{first:08x}"
+
+
 def test_exact_math_device_matches_host(lrm, torch_cuda):
     """The device build of lrm_exact_math.h == its host build (itself checked against glibc
     in the CPU suite) on angles, coordinates and raw bit patterns."""
