@@ -77,6 +77,7 @@ def load():
         "lrm_positionability": [vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, vp, vp],
         "lrm_morton_order": [vp, sz, vp],
         "lrm_dbg_fast_host": [vp, sz, vp, vp, vp, vp, vp, vp, vp],
+        "lrm_dbg_fused_reach_host": [vp, sz, vp, vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
         "lrm_dbg_exact_math_dev": [vp, vp, sz, vp, vp, vp, vp],
         "lrm_dbg_sqrt_check_dev": [vp, vp],
@@ -276,6 +277,16 @@ def dbg_fast_host(xyz, leg, quat=None):
                                    _ptr(out["mask_unc"]), _ptr(out["dist"]), _ptr(out["valid"]),
                                    _ptr(out["dist_unc"])))
     return out
+
+
+def dbg_fused_reach_host(xyz, leg, quat=None):
+    """The fused kernel's reach-from-distance by-product on the host, no fallback -> (mask, doubt)."""
+    xyz = _f32(xyz, (-1, 3))
+    n = len(xyz)
+    mask, doubt = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    check(load().lrm_dbg_fused_reach_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask),
+                                          _ptr(doubt)))
+    return mask, doubt
 
 
 def positionability(bodies, targets, legs, quats, reference_culls=False):

@@ -493,6 +493,25 @@ int lrm_dbg_sqrt_check_dev(uint64_t* mismatches_out, uint32_t* first_bad_out) {
     return LRM_OK;
 }
 
+int lrm_dbg_fused_reach_host(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat,
+                             uint8_t* mask_out, uint8_t* doubt_out) {
+    if (!leg || (n && (!xyz || !mask_out || !doubt_out))) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    if (!L.fast_ok) return fail(LRM_EINVAL, "leg not eligible for the filtered evaluation");
+    const LrmDistTables T{&L.lists[0][0], &L.dist_tab[0][0], &L.corner_tab[0]};
+    for (size_t i = 0; i < n; i++) {
+        LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        uint32_t unc = 0;
+        LrmDistByproduct by;
+        lrm_dist_global_fast(L, T, p, unc, &by);
+        bool doubt;
+        mask_out[i] = lrm_reach_from_dist(L, by, doubt);
+        doubt_out[i] = doubt;
+    }
+    return LRM_OK;
+}
+
 // The filtered evaluation (lrm_point_fast.h) on the host, WITHOUT the strict fallback, with its
 // `uncertain` flags: tests check that every point not flagged equals the strict result and
 // count how many are flagged.  Outputs may be NULL.

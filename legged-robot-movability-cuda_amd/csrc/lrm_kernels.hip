@@ -70,6 +70,15 @@ __device__ __forceinline__ bool eval_dist(const LrmCompiledLeg& L, const LdsTabl
     if (kFast) return lrm_dist_global_filtered(L, LrmDistTables{t->lists, t->dist, t->corners}, p);
     return lrm_dist_global(L, t->lists, p);
 }
+// kOp 1: distance only; kOp 2: reach mask + distance (filtered mode: the mask is a by-product of
+// the distance evaluation, lrm_reach_from_dist)
+template <int kOp, bool kFast>
+__device__ __forceinline__ bool eval_reach_dist(const LrmCompiledLeg& L, const LdsTables* t, LrmVec3& p, bool& reach) {
+    if (kOp == 2 && kFast)
+        return lrm_reach_dist_global_filtered(L, LrmDistTables{t->lists, t->dist, t->corners}, p, reach);
+    if (kOp == 2) reach = eval_reach<kFast>(L, t, p);
+    return eval_dist<kFast>(L, t, p);
+}
 template <bool kFast>
 __device__ __forceinline__ bool eval_pair(const LrmCompiledLeg& L, const LdsTables* t, LrmVec3 tg, LrmVec3 body) {
     if (kFast) return lrm_reachable_rotate_leg_filtered(L, t->lists, t->lean, tg, body);
@@ -301,8 +310,7 @@ __global__ __launch_bounds__(kBlock, LRM_DIST_MIN_WAVES) void dist_soa_kernel(co
         bool m = false;
         if (i < n) {
             LrmVec3 p{x[i], y[i], z[i]};
-            if (kOp == 2) m = eval_reach<kFast>(L, &s_tab, p);
-            const bool v = eval_dist<kFast>(L, &s_tab, p);
+            const bool v = eval_reach_dist<kOp, kFast>(L, &s_tab, p, m);
             dx[i] = p.x;
             dy[i] = p.y;
             dz[i] = p.z;
@@ -343,8 +351,7 @@ __global__ __launch_bounds__(kBlock) void dist_aos_kernel(const float* __restric
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         bool m = false;
-        if (kOp == 2) m = eval_reach<kFast>(L, &s_tab, p);
-        const bool v = eval_dist<kFast>(L, &s_tab, p);
+        const bool v = eval_reach_dist<kOp, kFast>(L, &s_tab, p, m);
         dxyz[3 * i] = p.x;
         dxyz[3 * i + 1] = p.y;
         dxyz[3 * i + 2] = p.z;

@@ -241,6 +241,7 @@ LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, 
     lu |= !(magmin > 0.01f) ? 16u : 0u;           // at a circle centre the strict clamp switches direction (one_leg.cu:54-58)
     lu |= !(cv - av > tie) ? 32u : 0u;            // no candidate at all (inf - inf), or a three-way near-tie
     unc |= lu;
+    unc |= !(macc > 2.0f * band) ? 512u : 0u;     // statistic + the fused reach mask below: `overall` has less than twice the margin
     if (lu) { // strict evaluation of this call (rare: a few 1e-4 of the calls)
         x = x_in;
         y = y_in;
@@ -329,24 +330,38 @@ LRM_HD bool lrm_finish_closest_fast(const LrmCompiledLeg& L, const LrmDistTables
     return was_valid && !saturated;
 }
 
-LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& r, uint32_t& unc) {
+// What the fused reach+distance evaluation learns about reachability_global on the way (see
+// lrm_reach_from_dist).
+struct LrmDistByproduct {
+    bool res, resflip;      // finish_finding_closest of the direct / flipped candidate
+    uint32_t unc_flip;      // doubt bits of the flipped candidate's plane evaluation
+    float ax, ang, ang_flip; // coxa-frame x, the two candidate yaws
+};
+
+LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& r, uint32_t& unc,
+                                  LrmDistByproduct* by = nullptr) {
     LrmVec3 a = r;
     a.x -= L.body;
     float buffer = a.x * L.sin_pitch;
     a.x = a.x * L.cos_pitch - a.z * L.sin_pitch;
     a.z = buffer + a.z * L.cos_pitch;
     LrmVec3 b = a;
+    const float ax = a.x;
     const float ang = lrm_atan2f(a.y, a.x);
     const float ang_flip = (ang > 0) ? ang - LRM_PI_F : ang + LRM_PI_F;
     // one copy of the candidate evaluation, executed twice (halves the code the wave walks through)
     bool res = false, resflip = false;
+    uint32_t unc_flip = 0;
 #pragma unroll 1
     for (int k = 0; k < 2; k++) {
         LrmVec3 p = k ? b : a;
-        const bool r_k = lrm_finish_closest_fast(LRM_FRESH(L), T, p, k ? ang_flip : ang, unc);
-        if (k) { b = p; resflip = r_k; }
+        uint32_t u = 0;
+        const bool r_k = lrm_finish_closest_fast(LRM_FRESH(L), T, p, k ? ang_flip : ang, u);
+        unc |= u;
+        if (k) { b = p; resflip = r_k; unc_flip = u; }
         else { a = p; res = r_k; }
     }
+    if (by) *by = LrmDistByproduct{res, resflip, unc_flip, ax, ang, ang_flip};
     // The two candidates are often the same configuration up to rounding (yaw within 30 deg of
     // the axis: one of them is "mega-saturated" onto the other): the strict comparison of the
     // strict norms is the only way to pick the same one.
@@ -359,12 +374,38 @@ LRM_HD bool lrm_dist_circles_fast(const LrmCompiledLeg& L, const LrmDistTables T
     return res || resflip;
 }
 
-LRM_HD bool lrm_dist_global_fast(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& p, uint32_t& unc) {
+// reachability_global (one_leg.cu:280-319) from the by-products of distance_global on the same point.
+//
+// Both functions bring the point into the coxa frame with the same operations (qtRotate, z-rotation,
+// place_over_coxa), so they see the same (x, y, z) bit for bit.  reachability mirrors the point into
+// x >= 0, takes angle = atan2f(y, x) there, rejects it outside [min_coxa, max_coxa], cancels the yaw
+// with sincosf(-angle) and validates (fx - coxa_length, z) against the region's four circles.
+//  * sign bit of x clear: that is, operation for operation, the distance's DIRECT candidate -- same
+//    atan2f call, "saturated" <=> outside the yaw range, same sincosf argument when unsaturated, same
+//    rotated abscissa, and `was_valid` is the AND of the same four circle predicates
+//    (force_clamp_on_circle's `valid` = distance_to_circumf's, one_leg.cu:31-63) in the same region.
+//    So reach == res, identically (no band involved).
+//  * sign bit set: the mirrored yaw atan2f(-y, -x) and the flipped candidate's ang -+ pi differ by
+//    rounding (<= 2 ulp of pi), so res_flip is a FILTER for reach: it is the answer when the yaw is
+//    not within 2e-6 rad of a limit and, if the candidate is unsaturated, its plane evaluation kept
+//    twice the usual margin (the abscissa moves by < 1e-6 relative between the two yaws); otherwise
+//    the caller re-evaluates with the strict lrm_reach_global.
+//  * nan yaw (nan coordinates): doubt.
+LRM_HD bool lrm_reach_from_dist(const LrmCompiledLeg& L, const LrmDistByproduct& by, bool& doubt) {
+    const bool flipped = lrm_f2u(by.ax) >> 31;
+    const float lim_margin = fminf(fabsf(by.ang_flip - L.max_coxa), fabsf(by.ang_flip - L.min_coxa));
+    const bool flip_doubt = !(lim_margin > 2.0e-6f) || ((by.unc_flip & (1u | 512u)) != 0u);
+    doubt = !(fabsf(by.ang) <= 4.0f) || (flipped && flip_doubt);
+    return flipped ? by.resflip : by.res;
+}
+
+LRM_HD bool lrm_dist_global_fast(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& p, uint32_t& unc,
+                                 LrmDistByproduct* by = nullptr) {
     LrmVec3 u = lrm_qrot(L.inv_rot, p);
     float buffer = u.x * L.sin_body;
     u.x = u.x * L.cos_body - u.y * L.sin_body;
     u.y = buffer + u.y * L.cos_body;
-    const bool r = lrm_dist_circles_fast(L, T, u, unc);
+    const bool r = lrm_dist_circles_fast(L, T, u, unc, by);
     const LrmCompiledLeg& Le = LRM_FRESH(L);
     buffer = u.x * -Le.sin_body;
     u.x = u.x * Le.cos_body - u.y * -Le.sin_body;
@@ -396,4 +437,17 @@ LRM_HD bool lrm_reachable_rotate_leg_filtered(const LrmCompiledLeg& L, const Lrm
 LRM_HD bool lrm_dist_global_filtered(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& p) {
     uint32_t stat = 0; // the distance filter resolves its own doubts (see lrm_plane_dist_fast)
     return lrm_dist_global_fast(L, T, p, stat);
+}
+
+// reachability_global AND distance_global of one point: the mask comes out of the distance
+// evaluation (lrm_reach_from_dist), the strict reachability only runs for its rare doubts.
+LRM_HD bool lrm_reach_dist_global_filtered(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& p, bool& reach) {
+    const LrmVec3 p_in = p;
+    uint32_t stat = 0;
+    LrmDistByproduct by;
+    const bool v = lrm_dist_global_fast(L, T, p, stat, &by);
+    bool doubt;
+    reach = lrm_reach_from_dist(L, by, doubt);
+    if (doubt) reach = lrm_reach_global(L, T.lists, p_in);
+    return v;
 }

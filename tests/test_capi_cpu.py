@@ -134,6 +134,11 @@ def test_filtered_evaluation_on_host_matches_fixture(lrm, name):
     assert bits_equal(f["dist"], c["dist"]).all()
     if name.startswith("cube"):
         assert 1 - sure.mean() < 1e-3  # the strict fallback is rare on ordinary clouds
+    # the fused kernel's reach mask (a by-product of the distance evaluation, lrm_reach_from_dist)
+    fm, fd = lrm.dbg_fused_reach_host(c["points"], c["leg"], c["quat"])
+    assert np.array_equal(fm[fd == 0], c["mask"][fd == 0])
+    if name.startswith("cube"):
+        assert fd.mean() < 1e-3
 
 
 def test_filtered_evaluation_random_legs_and_clouds(lrm):
@@ -156,5 +161,7 @@ def test_filtered_evaluation_random_legs_and_clouds(lrm):
         sure = f["mask_unc"] == 0
         assert np.array_equal(f["mask"][sure], m[sure])
         assert np.array_equal(f["valid"], v) and bits_equal(f["dist"], d).all()
+        fm, fd = lrm.dbg_fused_reach_host(pts, leg, q)
+        assert np.array_equal(fm[fd == 0], m[fd == 0]) and fd.mean() < 2e-3
         checked += 1
     assert checked >= 8
