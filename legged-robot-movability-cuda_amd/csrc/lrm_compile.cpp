@@ -8,6 +8,7 @@
 // same expressions and the same libm calls yields the same floats, so hoisting does not
 // change a single result bit.  Compile without FMA contraction / fast-math.
 #include "lrm_compile.h"
+#include "lrm_point_fast.h" // LRM_BAND, LRM_BAND_DIST
 #include <cmath>
 #include <cstring>
 
@@ -338,14 +339,14 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
     for (int i = 0; i < LRM_N_CORNERS; i++)
         out->corner_tab[i] = (i < out->n_ucorners) ? circle(out->ucorner_x[i], out->ucorner_y[i], 0.f, true)
                                                    : circle(0.f, 0.f, 0.f, true);
-    out->band_q = (float)(4.0e-6 * 2.0 * (double)out->fast_scale);
+    out->band_q = (float)((double)LRM_BAND_DIST * 2.0 * (double)out->fast_scale);
 
     // One band for every test of the lean reach filter, linear in the L1 size of the input
     // point: the coxa-frame coordinates obey |x|+|y|+|z| <= sqrt(3) (|p|_1 + body), the affine map
     // is within 22u (|p|_1 + body) of the strict chain, the hardware sqrt within 8u r:
     //   S = fast_scale + (sqrt(3) + 1.5) (|p|_1 + body),  band = LRM_BAND * S.
     {
-        const double kBand = 4.0e-6; // LRM_BAND (lrm_point_fast.h)
+        const double kBand = (double)LRM_BAND;
         const double slope = 1.7320508 + 1.5;
         out->band_base = (float)(kBand * ((double)out->fast_scale + slope * std::fabs((double)l.body)));
         out->band_slope = (float)(kBand * slope);

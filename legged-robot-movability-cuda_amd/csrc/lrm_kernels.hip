@@ -30,7 +30,7 @@ constexpr int kBlock = 256;
 constexpr unsigned kLegArgSoA = 32, kLegArgAoS = 16;
 static_assert(alignof(LrmCompiledLeg) == 16 && sizeof(void*) == 8 && sizeof(size_t) == 8, "kernarg layout");
 #ifndef LRM_DIST_MIN_WAVES
-#define LRM_DIST_MIN_WAVES 4 // <= 128 VGPRs (4 waves/SIMD): measured 5 % faster than the unconstrained 141
+#define LRM_DIST_MIN_WAVES 5 // <= 96 VGPRs (5 waves/SIMD): 2 % faster than 4 waves, 6 waves spill (A/B on one box)
 #endif
 #ifndef LRM_REACH_MIN_WAVES
 #define LRM_REACH_MIN_WAVES 1

@@ -31,21 +31,26 @@
 //   m  = |p - c|^2 by FMA : relative error <= 2u;  v_sqrt_f32 / v_rsq_f32 : <= 1 ulp;
 //   strict d = r - sqrt(m) is exact by Sterbenz near the boundary, its sqrt carries 0.5 ulp
 //   => |d_fast - d_strict| <= 4u * mag <= 2.4e-7 * S,  S = |px| + |pz| + fast_scale.
-//   Band: LRM_BAND * S with LRM_BAND = 4e-6 (>= 16x).  Cross products t = cosC*pz - sinC*px:
-//   error <= 4u (|px| + |pz|), strict atan2f within 1 ulp of the true angle (2e-7 |p| in t): >= 8x.
-//   Arc form of the clamp validity: <= 12u * fast_scale against LRM_BAND * 2 * fast_scale (>= 10x).
+//   Band: LRM_BAND_DIST * S with LRM_BAND_DIST = 2e-6 (>= 8x).  Cross products t = cosC*pz - sinC*px:
+//   error <= 4u (|px| + |pz|), strict atan2f within 1 ulp of the true angle (2e-7 |p| in t): >= 4x.
+//   Arc form of the clamp validity: <= 12u * fast_scale against LRM_BAND_DIST * 2 * fast_scale (>= 5x).
 // Reach filter: the coxa-frame point itself is approximate (one FMA affine map instead of the
 // strict qtRotate / z-rotation / translation / pitch chain: <= 22u (|p|_1 + body) apart) and the
 // plane abscissa is sgn(x) sqrt(x^2 + y^2) instead of x cos(a) - y sin(a) (<= 8u r apart):
-//   band = LRM_BAND * (fast_scale + (sqrt(3) + 1.5) (|p|_1 + body))   (>= 4.5x, linear in |p|_1).
+//   band = LRM_BAND * (fast_scale + (sqrt(3) + 1.5) (|p|_1 + body)), LRM_BAND = 4e-6 (>= 4.5x, linear in |p|_1).
 // Empirical margin (tests/test_capi_cpu.py keeps the bands honest on every fixture, including the
-// boundary-hugging one): shrinking LRM_BAND 40x (to 1e-7) still gives zero mismatches on 6e6
-// points x 6 leg/orientation cases; the first mismatches appear at 2e-8 (200x smaller).
+// boundary-hugging one): with both bands at 1e-7 there are still zero mismatches on 6e6 points x 6
+// leg/orientation cases; the first mismatches appear at 2e-8 (100-200x smaller than the bands in use).
+// The distance band is the tighter one because its doubts cost more: a wave re-runs the strict
+// plane evaluation (~800 instructions) when ANY of its 64 lanes is in doubt.
 #pragma once
 #include "lrm_point.h"
 
 #ifndef LRM_BAND
 #define LRM_BAND 4.0e-6f
+#endif
+#ifndef LRM_BAND_DIST
+#define LRM_BAND_DIST 2.0e-6f
 #endif
 
 // Device kernels that read the leg from the kernarg segment define LRM_FRESH as lrm_fresh: the
@@ -174,7 +179,7 @@ struct LrmDistTables {
 LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, float& x, float& y, uint32_t& unc) {
     const float x_in = x, y_in = y;
     x -= L.coxa_length;
-    const float band = LRM_BAND * (fabsf(x) + fabsf(y) + L.fast_scale);
+    const float band = LRM_BAND_DIST * (fabsf(x) + fabsf(y) + L.fast_scale);
     // region (circles.cu.h:48-78)
     const float t_mid = __builtin_fmaf(L.dir_cos[0], y, -(L.dir_sin[0] * x));
     const float t_s0 = __builtin_fmaf(L.dir_cos[1], y, -(L.dir_sin[1] * x));

@@ -118,6 +118,6 @@ struct LrmCompiledLeg {
         } arc[3];
     } dist_tab[4][LRM_N_CIRCLES];
     LrmCircle corner_tab[LRM_N_CORNERS]; // de-duplicated corner points as zero-radius circles
-    float band_q;                        // LRM_BAND * 2 * fast_scale: clamp points live on the circles
+    float band_q;                        // LRM_BAND_DIST * 2 * fast_scale: clamp points live on the circles
     float pad3_[3];
 };
