@@ -329,9 +329,10 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
                 const LrmCircle& cj = out->lists[k][j];
                 const double ex = (double)ci.x - (double)cj.x, ey = (double)ci.y - (double)cj.y;
                 const double gsj = (double)out->flists[k][j].sg / (double)out->flists[k][j].g;
-                d.arc[a].ex = (float)ex;
-                d.arc[a].ey = (float)ey;
-                d.arc[a].P = (float)(2.0 * (double)ci.r * gsj);
+                const double P = 2.0 * (double)ci.r * gsj;
+                d.arc[a].ex = (float)(ex * P); // the direction comes pre-scaled by P: one multiply less per arc
+                d.arc[a].ey = (float)(ey * P);
+                d.arc[a].P = (float)P;
                 d.arc[a].Q = (float)((ex * ex + ey * ey + (double)ci.r * (double)ci.r - (double)out->flists[k][j].T) * gsj);
                 a++;
             }

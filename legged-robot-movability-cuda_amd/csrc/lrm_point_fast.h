@@ -67,6 +67,17 @@
 #define LRM_FAST_RSQ(v) (1.0f / sqrtf(v))
 #endif
 
+LRM_HD uint32_t lrm_umed3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c > hi ? hi : c);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------
 // reachability: decisions only.  Lean form: one affine map into the coxa frame, every test
 // turned into a signed distance-to-the-decision-boundary in mm ("value"); the decision is the
@@ -202,12 +213,9 @@ LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, 
         magmin = fminf(magmin, mag);
         const float ad = fabsf(d.r - mag);
         // validity of the clamp point against the other three circles, in arc form
-        const float w0 = __builtin_fmaf(vx, d.arc[0].ex, vy * d.arc[0].ey) * rs;
-        const float w1 = __builtin_fmaf(vx, d.arc[1].ex, vy * d.arc[1].ey) * rs;
-        const float w2 = __builtin_fmaf(vx, d.arc[2].ex, vy * d.arc[2].ey) * rs;
-        const float q0 = __builtin_fmaf(w0, d.arc[0].P, d.arc[0].Q);
-        const float q1 = __builtin_fmaf(w1, d.arc[1].P, d.arc[1].Q);
-        const float q2 = __builtin_fmaf(w2, d.arc[2].P, d.arc[2].Q);
+        const float q0 = __builtin_fmaf(__builtin_fmaf(vx, d.arc[0].ex, vy * d.arc[0].ey), rs, d.arc[0].Q);
+        const float q1 = __builtin_fmaf(__builtin_fmaf(vx, d.arc[1].ex, vy * d.arc[1].ey), rs, d.arc[1].Q);
+        const float q2 = __builtin_fmaf(__builtin_fmaf(vx, d.arc[2].ex, vy * d.arc[2].ey), rs, d.arc[2].Q);
         const float okv = fmaxf(fmaxf(q0, q1), q2);
         maccq = fminf(maccq, fminf(fminf(fabsf(q0), fabsf(q1)), fabsf(q2)));
         // an invalid clamp ranks as +inf (exponent all ones, mantissa = candidate number only)
@@ -218,12 +226,11 @@ LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, 
     uint32_t a = key[0] < key[1] ? key[0] : key[1];
     uint32_t b = key[0] < key[1] ? key[1] : key[0];
     uint32_t c = 0x7f80000fu;
-    auto insert = [&](uint32_t k) {
-        const uint32_t t1 = a > k ? a : k;
+    auto insert = [&](uint32_t k) { // a <= b <= c stay the three smallest: four operations
+        const uint32_t bk = b > k ? b : k;       // max(a, b, k) since a <= b
+        c = c < bk ? c : bk;
+        b = lrm_umed3(a, b, k);
         a = a < k ? a : k;
-        const uint32_t t2 = b > t1 ? b : t1;
-        b = b < t1 ? b : t1;
-        c = c < t2 ? c : t2;
     };
     insert(key[2]);
     insert(key[3]);

@@ -109,7 +109,7 @@ struct LrmCompiledLeg {
     // Per circle i of a list: the point-validity record, r, and for each other circle j the
     // "arc" record that answers "is the clamp point of i valid for j" without building the clamp
     // point:  val_ij = P * ((p - c_i) . e_ij / |p - c_i|) + Q  (mm, < 0 = valid), with
-    // e_ij = c_i - c_j, P = 2 r_i gs_j, Q = (|e_ij|^2 + r_i^2 - T_j) gs_j.
+    // e_ij = c_i - c_j, P = 2 r_i gs_j, Q = (|e_ij|^2 + r_i^2 - T_j) gs_j.  (ex, ey) hold P * e_ij.
     struct alignas(16) DistCircle {
         float x, y, gs, c;
         float r, attract, pad0, pad1;
