@@ -324,8 +324,11 @@ LRM_HD bool lrm_finish_closest_fast(const LrmCompiledLeg& L, const LrmDistTables
         if (near || nrm > d_lim) {
             // strict arithmetic (one_leg.cu:258-272): decides when `near`, and produces the output
             unc |= near ? 64u : 0u;
-            float s2, c2;
-            lrm_sincosf(th, &s2, &c2);
+            // A candidate clamped to a yaw limit has th = -(limit - sat) = -0: sincosf(+-0) = (+-0, 1)
+            // exactly, and those are most of the lanes that come here with the flipped candidate --
+            // the polynomial only runs when some lane of the wave has a real angle.
+            float s2 = th, c2 = 1.0f;
+            if (th != 0.f) lrm_sincosf(th, &s2, &c2);
             const float sy = save.x * s2 + save.y * c2;
             LrmVec3 lim = {0.f, sy, 0.f};
             if (lrm_norm3(p) > lrm_norm3(lim)) {
