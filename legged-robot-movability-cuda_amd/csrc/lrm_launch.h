@@ -16,13 +16,14 @@ hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmComp
                                float* dxyz, bool fast, hipStream_t st);
 hipError_t lrm_launch_reach_any(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
                                 const float* ty, const float* tz, size_t nt, const LrmCompiledLeg* legs_dev,
-                                int nlegs, float* tile_boxes /* ntiles x 6 floats of workspace, or null */,
+                                int nlegs, float* tile_boxes /* 17 x ntiles x 6 floats of workspace, or null */,
+                                bool boxes_ready /* the workspace already holds this cloud's boxes */,
                                 const uint8_t* body_active /* null = all */, uint8_t* out_leg_body,
                                 uint8_t* all_legs_out, bool fast, hipStream_t st);
 hipError_t lrm_launch_any_in_shape(int shape, const float* cx, const float* cy, const float* cz, size_t nc,
                                    const float* tx, const float* ty, const float* tz, size_t nt, float radius,
-                                   float plus_z, float minus_z, float* tile_boxes /* workspace or null */, uint8_t* out,
-                                   hipStream_t st);
+                                   float plus_z, float minus_z, float* tile_boxes /* workspace or null */,
+                                   bool boxes_ready, uint8_t* out, hipStream_t st);
 hipError_t lrm_launch_sqrt_check(unsigned long long* counters_dev /* [2]: mismatches, first bad pattern + 1 */,
                                  hipStream_t st);
 hipError_t lrm_launch_exact_math(const float* a, const float* b, size_t n, float* at2, float* sn, float* cs,
