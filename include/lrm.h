@@ -226,6 +226,11 @@ int lrm_dbg_sqrt_check_dev(uint64_t* mismatches_out, uint32_t* first_bad_out);
 int lrm_dbg_fast_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                       uint8_t* mask_out, uint8_t* mask_uncertain_out, float* dxyz_aos_out,
                       uint8_t* valid_out, uint8_t* dist_uncertain_out);
+/* The per-leg bounding sphere the pair kernels use to skip batches of footholds:
+ * out4 = {cx, cy, cz (relative to the body position), squared radius}.  Tests check that every
+ * pair the strict reachable_rotate_leg accepts lies inside. */
+int lrm_dbg_pair_sphere(const LrmLegDimensions* leg, const float* quat, float* out4);
+
 /* The reach mask the fused filtered kernel derives from its distance evaluation
  * (lrm_reach_from_dist, csrc/lrm_point_fast.h), WITHOUT the strict fallback, and the per-point
  * doubt flag that would trigger it. */

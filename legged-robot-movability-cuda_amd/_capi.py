@@ -78,6 +78,7 @@ def load():
         "lrm_morton_order": [vp, sz, vp],
         "lrm_dbg_fast_host": [vp, sz, vp, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_fused_reach_host": [vp, sz, vp, vp, vp, vp],
+        "lrm_dbg_pair_sphere": [vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
         "lrm_dbg_exact_math_dev": [vp, vp, sz, vp, vp, vp, vp],
         "lrm_dbg_sqrt_check_dev": [vp, vp],
@@ -277,6 +278,13 @@ def dbg_fast_host(xyz, leg, quat=None):
                                    _ptr(out["mask_unc"]), _ptr(out["dist"]), _ptr(out["valid"]),
                                    _ptr(out["dist_unc"])))
     return out
+
+
+def dbg_pair_sphere(leg, quat=None):
+    """Bounding sphere of the pair test of one leg -> (centre[3] relative to the body position, r^2)."""
+    out = np.zeros(4, np.float32)
+    check(load().lrm_dbg_pair_sphere(_ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(out)))
+    return out[:3].copy(), float(out[3])
 
 
 def dbg_fused_reach_host(xyz, leg, quat=None):

@@ -496,6 +496,15 @@ int lrm_dbg_sqrt_check_dev(uint64_t* mismatches_out, uint32_t* first_bad_out) {
     return LRM_OK;
 }
 
+int lrm_dbg_pair_sphere(const LrmLegDimensions* leg, const float* quat, float* out4) {
+    if (!leg || !out4) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 0, &L);
+    for (int k = 0; k < 3; k++) out4[k] = L.pair_center[k];
+    out4[3] = L.pair_r2;
+    return LRM_OK;
+}
+
 int lrm_dbg_fused_reach_host(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat,
                              uint8_t* mask_out, uint8_t* doubt_out) {
     if (!leg || (n && (!xyz || !mask_out || !doubt_out))) return fail(LRM_EINVAL, "null argument");

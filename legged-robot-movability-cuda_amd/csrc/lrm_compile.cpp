@@ -9,6 +9,7 @@
 // change a single result bit.  Compile without FMA contraction / fast-math.
 #include "lrm_compile.h"
 #include "lrm_point_fast.h" // LRM_BAND, LRM_BAND_DIST
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -305,6 +306,40 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
             out->aff_pair[4 * r + 3] = tr;
         }
         for (int k = 0; k < 3; k++) out->grav_row[k] = (float)RzRq[0][k];
+        // Per-leg bounding sphere of the pair test.  In the coxa frame a reachable foothold has its
+        // (mirrored) yaw in [min_coxa, max_coxa] and lies within L = femur + tibia (+ slack) of the
+        // femur joint in its meridian plane: (r - c)^2 + z^2 <= L^2 with r >= 0, c = coxa_length, or,
+        // for a point behind the coxa axis (the reference mirrors it and evaluates px = -r - c),
+        // (r' + c)^2 + z^2 <= L^2 at yaw + pi.  For a centre at radius rho on the bisector of the yaw
+        // range (half-width al) the squared distance is linear in r on each part, so its maximum is
+        //   max( rho^2 + L^2 - c^2 + 2 (L - c)+ (rho - c)+ ,  (c + L)^2 - 2 rho (c + L) cos(al) + rho^2 ).
+        {
+            const double c = l.coxa_length, L = ((double)l.femur_length + (double)l.tibia_length + 1.0) * 1.0001;
+            const double th = 0.5 * ((double)out->max_coxa + (double)out->min_coxa);
+            const double ca = std::cos(0.5 * ((double)out->max_coxa - (double)out->min_coxa));
+            auto radius2 = [&](double rho) {
+                const double f1 = rho * rho + L * L - c * c + 2.0 * std::max(L - c, 0.0) * std::max(rho - c, 0.0);
+                const double f2 = (c + L) * (c + L) - 2.0 * rho * (c + L) * ca + rho * rho;
+                return std::max(f1, f2);
+            };
+            double rho = 0.0, r2 = (std::fabs(c) + L) * (std::fabs(c) + L); // the whole ball around the coxa origin
+            if (ca > 0.05 && c > 0 && std::isfinite(th)) {
+                const double cand[3] = {c, 2.0 * c * L / (std::max(L - c, 0.0) + (c + L) * ca), c / ca};
+                for (double rc : cand)
+                    if (radius2(rc) < r2) {
+                        r2 = radius2(rc);
+                        rho = rc;
+                    }
+            }
+            // centre in the coxa frame -> relative to the body position: x_coxa = Rp (Rz t - (body, 0, 0))
+            const double cc[3] = {rho * std::cos(th), rho * std::sin(th), 0.0};
+            double v[3];
+            for (int k = 0; k < 3; k++) v[k] = Rp[0][k] * cc[0] + Rp[1][k] * cc[1] + Rp[2][k] * cc[2];
+            v[0] += (double)l.body;
+            for (int k = 0; k < 3; k++) out->pair_center[k] = (float)(Rz[0][k] * v[0] + Rz[1][k] * v[1] + Rz[2][k] * v[2]);
+            const double rr = std::sqrt(r2) + 1.0; // + 1 mm: float rounding of the centre and of the test itself
+            out->pair_r2 = (float)(rr * rr * 1.0001);
+        }
         for (int k = 0; k < 4; k++)
             for (int i = 0; i < LRM_N_CIRCLES; i++) {
                 auto& q = out->lean[k][i];

@@ -608,10 +608,16 @@ __global__ __launch_bounds__(kBlock, LRM_ANY_WAVE_MIN_WAVES) void reach_any_wave
         auto process = [&](int m) {
             LrmVec3 t{0.f, 0.f, 0.f};
             if (lane < m) t = LrmVec3{qx[lane], qy[lane], qz[lane]};
+            const float rx = t.x - body.x, ry = t.y - body.y, rz = t.z - body.z;
             for (int l = 0; l < nlegs; l++) {
                 if ((found >> l) & 1u) continue; // wave-uniform
+                // the leg's own bounding sphere: a batch is a patch of neighbouring footholds and
+                // mostly lies outside the spheres of all but two or three legs
+                const float ex = rx - legs[l].pair_center[0], ey = ry - legs[l].pair_center[1], ez = rz - legs[l].pair_center[2];
+                const bool inside = (lane < m) && __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) <= legs[l].pair_r2;
+                if (__ballot(inside) == 0ull) continue;
                 bool hit = false;
-                if (lane < m) {
+                if (inside) {
                     if (kFast) hit = lrm_reachable_rotate_leg_filtered(legs[l], &legs[l].lists[0][0], s_lean[l], t, body);
                     else hit = lrm_reachable_rotate_leg(legs[l], &legs[l].lists[0][0], t, body);
                 }

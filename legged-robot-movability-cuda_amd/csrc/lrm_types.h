@@ -98,6 +98,11 @@ struct LrmCompiledLeg {
     float aff_pair[12];
     float grav_row[3];                  // x row of Rz * Rq: the "gravity side" test of reachable_rotate_leg
     float pad2_[1];
+    // bounding sphere (centre relative to the body position, squared radius with slack) of everything
+    // reachable_rotate_leg can accept for THIS leg: see lrm_compile.cpp.  The pair kernels skip a batch
+    // of footholds for a leg when none of them is inside.
+    float pair_center[3];
+    float pair_r2;
     // one 16-byte record per circle of a list: v = m * gs + c with m = |p - centre|^2,
     // gs = sg / (2 (r + margin)), c = -T * gs: the point is valid <=> v < 0, and |v| is its
     // distance (mm) to that decision boundary

@@ -165,3 +165,28 @@ def test_filtered_evaluation_random_legs_and_clouds(lrm):
         assert np.array_equal(fm[fd == 0], m[fd == 0]) and fd.mean() < 2e-3
         checked += 1
     assert checked >= 8
+
+
+def test_pair_bounding_sphere_contains_every_reachable_pair(lrm, oracle):
+    """The per-leg sphere with which the pair kernels skip batches of footholds must contain every
+    (foothold - body) the strict reachable_rotate_leg accepts: dense samples around the leg, the two
+    committed legs at several mounts plus random legs, random body orientations."""
+    rng = np.random.default_rng(77)
+    legs = [lrm.get_M2_leg(a) for a in (0.0, 1.0471976, 2.0943952, 3.1415927, -1.0471976)]
+    legs += [lrm.get_moonbot_leg(a) for a in (0.0, 1.5707964)]
+    for _ in range(6):
+        legs.append(lrm.leg_factory(rng.uniform(-3, 3), rng.uniform(80, 250), rng.uniform(-60, 30), rng.uniform(30, 90),
+                                    rng.uniform(90, 160), rng.uniform(90, 170), rng.uniform(30, 80), rng.uniform(60, 100),
+                                    rng.uniform(90, 140), rng.uniform(-20, 10), rng.uniform(-20, 10)))
+    reachable_seen = 0
+    for i, leg in enumerate(legs):
+        q = np.array([1, 0, 0, 0], np.float32) if i % 2 == 0 else (rng.normal(size=4) + [3, 0, 0, 0]).astype(np.float32)
+        centre, r2 = lrm.dbg_pair_sphere(leg, q)
+        rel = rng.uniform(-700, 700, (150_000, 3)).astype(np.float32)
+        # reach(body, target) depends on target - body only: one target at the origin, bodies at -rel
+        hit = oracle.reach_any(-rel, np.zeros((1, 3), np.float32), [leg], q)[0].astype(bool)
+        d2 = ((rel[hit].astype(np.float64) - centre) ** 2).sum(axis=1)
+        assert (d2 <= r2).all(), (i, float(d2.max()), r2)
+        reachable_seen += int(hit.sum())
+        assert r2 < 0.75 * (float(leg[1]) + float(leg[3]) + float(leg[4]) + float(leg[5]) + 1) ** 2 or float(leg[3]) <= 0
+    assert reachable_seen > 5000
