@@ -11,6 +11,7 @@
 //
 // Compiled with -ffp-contract=off (see lrm_point.h).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <algorithm>
 #include "lrm_launch.h"
@@ -26,10 +27,20 @@ constexpr int kBlock = 256;
 // allocation, graph-capturable) but read it through lrm_kernarg<>(offset) rather than through the
 // parameter: the parameter's loads are hoisted to the top of the kernel, overflow the SGPR file
 // (98 SGPR spills, ~150 v_readlane per point in the fused kernel), and its address cannot be
-// taken without a 2.7 KB/lane scratch copy.  Offsets follow the kernarg layout (natural
-// alignment): x, y, z, n -> 32;  xyz, n -> 16.
-constexpr unsigned kLegArgSoA = 32, kLegArgAoS = 16;
-static_assert(alignof(LrmCompiledLeg) == 16 && sizeof(void*) == 8 && sizeof(size_t) == 8, "kernarg layout");
+// taken without a 2.7 KB/lane scratch copy.  The kernarg segment is laid out like a C struct of
+// the parameters in order (natural alignment), mirrored by KernargSoA / KernargAoS.
+struct KernargSoA { // the leading parameters of the SoA kernels, in order
+    const float *x, *y, *z;
+    size_t n;
+    LrmCompiledLeg L;
+};
+struct KernargAoS { // ... of the AoS kernels
+    const float* xyz;
+    size_t n;
+    LrmCompiledLeg L;
+};
+constexpr unsigned kLegArgSoA = (unsigned)offsetof(KernargSoA, L), kLegArgAoS = (unsigned)offsetof(KernargAoS, L);
+static_assert(kLegArgSoA == 32 && kLegArgAoS == 16, "kernarg layout");
 #ifndef LRM_DIST_MIN_WAVES
 #define LRM_DIST_MIN_WAVES 5 // <= 96 VGPRs (5 waves/SIMD): 2 % faster than 4 waves, 6 waves spill (A/B on one box)
 #endif
