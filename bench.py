@@ -96,8 +96,10 @@ def cpu_baseline(sample_points, leg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the GPU needs ~50 ms of sustained load to reach its steady clocks (20 steps after 3
+    # warm-up steps measure 0.26 ms/step, 500 after 100 measure 0.22); 600 steps are 0.15 s of GPU time
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--points", type=int, default=10_000_000, help="targets per GPU")
     ap.add_argument("--mode", choices=["strict", "fast"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -190,8 +192,9 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     # secondary figures (not part of the timed region): reach-only and distance-only kernels
-    def time_kernel(fn, reps=10):
-        fn()
+    def time_kernel(fn, reps=100):
+        for _ in range(20):
+            fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
