@@ -19,7 +19,8 @@ def main():
     ap.add_argument("--bodies", type=int, default=100_000)
     ap.add_argument("--terrain-side", type=int, default=316)  # 316^2 = 99 856 points
     ap.add_argument("--legs", type=int, default=6)
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--warm", type=int, default=50, help="untimed launches first: the GPU needs ~50 ms of load to reach its steady clocks")
     ap.add_argument("--check", type=int, default=0, help="verify this many random bodies against the oracle")
     ap.add_argument("--mode", choices=["strict", "fast"], default="fast")
     ap.add_argument("--morton", action="store_true", help="feed both clouds in Morton order (lrm_morton_order)")
@@ -41,7 +42,8 @@ def main():
     out = torch.empty((len(legs), len(bodies)), dtype=torch.uint8, device="cuda")
     alll = torch.empty(len(bodies), dtype=torch.uint8, device="cuda")
     run = lambda: lrm_amd.device.reach_any(tb[0], tb[1], tb[2], tt[0], tt[1], tt[2], legs, None, out=out, all_legs=alll)
-    run()
+    for _ in range(max(args.warm, 1)):
+        run()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
