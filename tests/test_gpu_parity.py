@@ -231,6 +231,46 @@ def test_non_finite_and_extreme_inputs(lrm, oracle, torch_cuda):
             assert np.array_equal(m.cpu().numpy(), oracle.reach(g, leg, qq))
             assert np.array_equal(v.cpu().numpy(), want_v)
             assert bits_equal(d.cpu().numpy().T, want_d).all()
+            # the fused kernel derives its mask from the distance evaluation (lrm_reach_from_dist)
+            mf, df = lrm.device.reach_dist(x, y, z, leg, q)
+            torch_cuda.cuda.synchronize()
+            assert np.array_equal(mf.cpu().numpy(), oracle.reach(g, leg, qq))
+            assert bits_equal(df.cpu().numpy().T, want_d).all()
+
+
+def test_fused_mask_on_points_behind_the_coxa_axis_and_on_yaw_limits(lrm, oracle, torch_cuda):
+    """The fused kernel takes the reach mask from the distance's direct candidate (coxa-frame x >= 0,
+    an identity) or filters it through the flipped candidate (x < 0): dense clouds around the coxa
+    axis, where points are mirrored, and on the yaw-limit planes, where the flipped candidate's yaw
+    is within rounding of the limit."""
+    rng = np.random.default_rng(11)
+    for leg in (lrm.get_M2_leg(0.0), lrm.get_M2_leg(2.0943952), lrm.get_moonbot_leg(0.7)):
+        body, pitch, coxa = float(leg[1]), float(leg[2]), float(leg[3])
+        n = 400_000
+        # (a) a slab around the coxa axis (coxa-frame x ~ 0), in the leg's own azimuth frame
+        a = np.stack([body + rng.normal(0, 30, n), rng.uniform(-400, 400, n), rng.uniform(-400, 200, n)], 1)
+        # (b) points on the two yaw-limit planes, on both sides of the axis, with ulp-scale scatter
+        r = rng.uniform(-400, 400, n)
+        lim = np.where(rng.random(n) < 0.5, float(leg[8]), float(leg[9])) + rng.normal(0, 2e-7, n)
+        zc = rng.uniform(-300, 200, n)
+        xc, yc = r * np.cos(lim), r * np.sin(lim)
+        # undo place_over_coxa (x -= body, then (x, z) rotated by -pitch): rotate by +pitch, add the body offset
+        b = np.stack([xc * np.cos(pitch) - zc * np.sin(pitch) + body, yc, xc * np.sin(pitch) + zc * np.cos(pitch)], 1)
+        ang = float(leg[0])
+        pts = np.concatenate([a, b]).astype(np.float64)
+        rot = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+        pts = (pts @ rot.T).astype(np.float32)  # leg azimuth frame -> body frame
+        x, y, z = soa(torch_cuda, pts)
+        for q in (None, (0.97, 0.05, -0.1, 0.2)):
+            qq = (1, 0, 0, 0) if q is None else q
+            mf, df = lrm.device.reach_dist(x, y, z, leg, q)
+            torch_cuda.cuda.synchronize()
+            want_m = oracle.reach(pts, leg, qq)
+            want_d, _ = oracle.dist(pts, leg, qq)
+            assert np.array_equal(mf.cpu().numpy(), want_m)
+            assert bits_equal(df.cpu().numpy().T, want_d).all()
+            if q is None:
+                assert 0.001 < want_m.mean() < 0.9
 
 
 def test_config4_cloud_1e8_points_on_one_gpu(lrm, oracle, torch_cuda, mode):
