@@ -42,7 +42,10 @@ struct KernargAoS { // ... of the AoS kernels
 constexpr unsigned kLegArgSoA = (unsigned)offsetof(KernargSoA, L), kLegArgAoS = (unsigned)offsetof(KernargAoS, L);
 static_assert(kLegArgSoA == 32 && kLegArgAoS == 16, "kernarg layout");
 #ifndef LRM_DIST_MIN_WAVES
-#define LRM_DIST_MIN_WAVES 5 // <= 96 VGPRs (5 waves/SIMD): 2 % faster than 4 waves, 6 waves spill (A/B on one box)
+#define LRM_DIST_MIN_WAVES 5 // <= 96 VGPRs (5 waves/SIMD): 10 % faster than 4 waves at steady clocks (0.216 / 0.239 ms), 6 waves spill
+#endif
+#ifndef LRM_DIST_GRID_MULT
+#define LRM_DIST_GRID_MULT 8 // workgroups launched per resident workgroup (see lrm_launch_dist_soa): 4 / 8 / 16 / 32 -> 0.220 / 0.216 / 0.218 / 0.223 ms
 #endif
 #ifndef LRM_REACH_MIN_WAVES
 #define LRM_REACH_MIN_WAVES 1
@@ -993,7 +996,7 @@ hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const flo
     // Compute-bound with a data-dependent iteration time: 8x more workgroups than are resident
     // (256 CUs x LRM_DIST_MIN_WAVES) lets the dispatcher even out the tail -- 7 % faster than one
     // grid-stride wave set (sweep: 2048 -> 0.289 ms, 5120 -> 0.273, 10240..20480 -> 0.262-0.266).
-    const int grid = grid_for(n, 256 * LRM_DIST_MIN_WAVES * 8);
+    const int grid = grid_for(n, 256 * LRM_DIST_MIN_WAVES * LRM_DIST_GRID_MULT);
     if (op == 2 && fast) hipLaunchKernelGGL((dist_soa_kernel<2, true>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
     else if (op == 2) hipLaunchKernelGGL((dist_soa_kernel<2, false>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
     else if (fast) hipLaunchKernelGGL((dist_soa_kernel<1, true>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz);
