@@ -42,7 +42,14 @@ struct KernargAoS { // ... of the AoS kernels
 constexpr unsigned kLegArgSoA = (unsigned)offsetof(KernargSoA, L), kLegArgAoS = (unsigned)offsetof(KernargAoS, L);
 static_assert(kLegArgSoA == 32 && kLegArgAoS == 16, "kernarg layout");
 #ifndef LRM_DIST_MIN_WAVES
-#define LRM_DIST_MIN_WAVES 5 // <= 96 VGPRs (5 waves/SIMD): 10 % faster than 4 waves at steady clocks (0.216 / 0.239 ms), 6 waves spill
+// Waves per SIMD the filtered distance kernels are compiled for.  They are VALU-issue bound and the
+// full issue rate needs many waves: 4 / 5 waves (128 / 96 VGPRs) -> 0.239 / 0.216 ms at steady clocks; with
+// the circle loop of the filter unrolled by 2 instead of 4 (LRM_CIRCLE_UNROLL: fewer table values
+// live at once) 6 / 7 / 8 waves fit without scratch -> 0.207 / 0.203 / 0.205 ms.
+#define LRM_DIST_MIN_WAVES 7
+#endif
+#ifndef LRM_DIST_STRICT_MIN_WAVES
+#define LRM_DIST_STRICT_MIN_WAVES 5 // the strict kernels keep all four circles of a list in flight
 #endif
 #ifndef LRM_DIST_GRID_MULT
 #define LRM_DIST_GRID_MULT 8 // workgroups launched per resident workgroup (see lrm_launch_dist_soa): 4 / 8 / 16 / 32 -> 0.220 / 0.216 / 0.218 / 0.223 ms
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void reach_soa_scalar_kernel(const float* _
 // kOp: 1 = distance (+ optional validity byte), 2 = reach mask + distance.
 // ------------------------------------------------------------------------------------
 template <int kOp, bool kFast>
-__global__ __launch_bounds__(kBlock, LRM_DIST_MIN_WAVES) void dist_soa_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(kBlock, kFast ? LRM_DIST_MIN_WAVES : LRM_DIST_STRICT_MIN_WAVES) void dist_soa_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ y,
                                                           const float* __restrict__ z, size_t n,
                                                           const LrmCompiledLeg L_kernarg,
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void reach_aos_kernel(const float* __restri
 }
 
 template <int kOp, bool kFast>
-__global__ __launch_bounds__(kBlock) void dist_aos_kernel(const float* __restrict__ xyz, size_t n,
+__global__ __launch_bounds__(kBlock, kFast ? LRM_DIST_MIN_WAVES : LRM_DIST_STRICT_MIN_WAVES) void dist_aos_kernel(const float* __restrict__ xyz, size_t n,
                                                           const LrmCompiledLeg L_kernarg,
                                                           uint8_t* __restrict__ mask,
                                                           float* __restrict__ dxyz) {

@@ -49,6 +49,12 @@
 #ifndef LRM_BAND
 #define LRM_BAND 4.0e-6f
 #endif
+// Unroll factor of the four-circle loop of lrm_plane_dist_fast.  4 keeps all four circle records
+// (80 table values) in flight; 2 halves that and lets the distance kernels run 7 waves/SIMD, which
+// is worth more (see LRM_DIST_MIN_WAVES in lrm_kernels.hip).
+#ifndef LRM_CIRCLE_UNROLL
+#define LRM_CIRCLE_UNROLL 2
+#endif
 #ifndef LRM_BAND_DIST
 #define LRM_BAND_DIST 2.0e-6f
 #endif
@@ -199,6 +205,7 @@ LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, 
     float macc = fminf(fminf(fabsf(t_mid), fabsf(t_s0)), fminf(fabsf(t_s1), fmaxf(x, fabsf(y))));
     float maccq = 3.0e38f, magmin = 3.0e38f, vacc = -3.0e38f;
     const LrmCompiledLeg::DistCircle* dt = T.dist + reg;
+#if LRM_CIRCLE_UNROLL == 4
     uint32_t key[LRM_N_CIRCLES];
 #pragma unroll
     for (int i = 0; i < LRM_N_CIRCLES; i++) {
@@ -234,6 +241,36 @@ LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, 
     };
     insert(key[2]);
     insert(key[3]);
+#else
+    // rolled variant (fewer table values live at once): the keys are inserted as they are produced
+    uint32_t a = 0x7f80000fu, b = 0x7f80000fu, c = 0x7f80000fu;
+    auto insert = [&](uint32_t k) { // a <= b <= c stay the three smallest: four operations
+        const uint32_t bk = b > k ? b : k;       // max(a, b, k) since a <= b
+        c = c < bk ? c : bk;
+        b = lrm_umed3(a, b, k);
+        a = a < k ? a : k;
+    };
+#pragma unroll LRM_CIRCLE_UNROLL
+    for (int i = 0; i < LRM_N_CIRCLES; i++) {
+        const LrmCompiledLeg::DistCircle d = dt[i];
+        const float vx = x - d.x, vy = y - d.y;
+        const float m = __builtin_fmaf(vy, vy, vx * vx);
+        const float pv = __builtin_fmaf(m, d.gs, d.c);
+        vacc = fmaxf(vacc, pv);
+        macc = fminf(macc, fabsf(pv));
+        const float rs = LRM_FAST_RSQ(m);
+        const float mag = m * rs;
+        magmin = fminf(magmin, mag);
+        const float ad = fabsf(d.r - mag);
+        const float q0 = __builtin_fmaf(__builtin_fmaf(vx, d.arc[0].ex, vy * d.arc[0].ey), rs, d.arc[0].Q);
+        const float q1 = __builtin_fmaf(__builtin_fmaf(vx, d.arc[1].ex, vy * d.arc[1].ey), rs, d.arc[1].Q);
+        const float q2 = __builtin_fmaf(__builtin_fmaf(vx, d.arc[2].ex, vy * d.arc[2].ey), rs, d.arc[2].Q);
+        const float okv = fmaxf(fmaxf(q0, q1), q2);
+        maccq = fminf(maccq, fminf(fminf(fabsf(q0), fabsf(q1)), fabsf(q2)));
+        insert(((okv < 0.f) ? (lrm_f2u(ad) & ~15u) : 0x7f800000u) | (uint32_t)i);
+    }
+    const bool overall = vacc < 0.f;
+#endif
     // corner points only matter when the origin is invalid (one_leg.cu:109-116)
     const uint32_t corner_keep = overall ? 0u : 0xffffffffu;
 #pragma unroll
