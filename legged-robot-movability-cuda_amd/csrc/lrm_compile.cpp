@@ -357,7 +357,7 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
             auto& d = out->dist_tab[k][i];
             const LrmCircle& ci = out->lists[k][i];
             d.x = ci.x; d.y = ci.y; d.gs = out->lean[k][i].gs; d.c = out->lean[k][i].c;
-            d.r = ci.r; d.attract = ci.attract; d.pad0 = d.pad1 = 0.f;
+            d.r = ci.r; d.pad[0] = d.pad[1] = 0.f;
             int a = 0;
             for (int j = 0; j < LRM_N_CIRCLES; j++) {
                 if (j == i) continue;
@@ -367,7 +367,6 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
                 const double P = 2.0 * (double)ci.r * gsj;
                 d.arc[a].ex = (float)(ex * P); // the direction comes pre-scaled by P: one multiply less per arc
                 d.arc[a].ey = (float)(ey * P);
-                d.arc[a].P = (float)P;
                 d.arc[a].Q = (float)((ex * ex + ey * ey + (double)ci.r * (double)ci.r - (double)out->flists[k][j].T) * gsj);
                 a++;
             }

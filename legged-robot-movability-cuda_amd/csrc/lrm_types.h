@@ -115,12 +115,14 @@ struct LrmCompiledLeg {
     // "arc" record that answers "is the clamp point of i valid for j" without building the clamp
     // point:  val_ij = P * ((p - c_i) . e_ij / |p - c_i|) + Q  (mm, < 0 = valid), with
     // e_ij = c_i - c_j, P = 2 r_i gs_j, Q = (|e_ij|^2 + r_i^2 - T_j) gs_j.  (ex, ey) hold P * e_ij.
+    // 64 bytes per circle, four ds_read_b128: {x, y, gs, c} {r, arc0} {arc1, arc2.ex} {arc2.ey, arc2.Q, -, -}
     struct alignas(16) DistCircle {
         float x, y, gs, c;
-        float r, attract, pad0, pad1;
-        struct alignas(16) Arc {
-            float ex, ey, P, Q;
+        float r;
+        struct Arc {
+            float ex, ey, Q;
         } arc[3];
+        float pad[2];
     } dist_tab[4][LRM_N_CIRCLES];
     LrmCircle corner_tab[LRM_N_CORNERS]; // de-duplicated corner points as zero-radius circles
     float band_q;                        // LRM_BAND_DIST * 2 * fast_scale: clamp points live on the circles
