@@ -608,8 +608,12 @@ __global__ __launch_bounds__(kBlock, LRM_ANY_WAVE_MIN_WAVES) void reach_any_wave
     const uint8_t* __restrict__ body_active /* null = all */, uint8_t* __restrict__ out, uint8_t* __restrict__ all_out) {
     __shared__ float s_qx[kWaves][kQueue], s_qy[kWaves][kQueue], s_qz[kWaves][kQueue];
     __shared__ LrmCompiledLeg::LeanCircle s_lean[LRM_MAX_LEGS][16];
+    __shared__ float s_sphere[LRM_MAX_LEGS][4]; // per-leg bounding sphere: centre (relative to the body), r^2
     for (int i = threadIdx.x; i < nlegs * 64; i += kBlock)
         reinterpret_cast<float*>(&s_lean[i >> 6][0])[i & 63] = reinterpret_cast<const float*>(&legs[i >> 6].lean[0][0])[i & 63];
+    if (threadIdx.x < nlegs * 4)
+        s_sphere[threadIdx.x >> 2][threadIdx.x & 3] =
+            (threadIdx.x & 3) < 3 ? legs[threadIdx.x >> 2].pair_center[threadIdx.x & 3] : legs[threadIdx.x >> 2].pair_r2;
     __syncthreads(); // the only one
     float r2max = 0.f;
     for (int l = 0; l < nlegs; l++) r2max = fmaxf(r2max, legs[l].reach_r2_max);
@@ -657,9 +661,21 @@ __global__ __launch_bounds__(kBlock, LRM_ANY_WAVE_MIN_WAVES) void reach_any_wave
                 near &= near - 1ull;
                 const size_t tile = tw0 + tb;
                 const size_t t0 = tile * kTargetTile;
-                // lane = chunk of this tile (empty chunks carry an inverted box: never near)
-                uint32_t cnear = (uint32_t)__ballot(
-                    lane < 16 && box_dist2(boxes + (ntiles + tile * 16 + lane) * 6, body.x, body.y, body.z) * 0.999f <= r2max);
+                // lane = (chunk of this tile, one of four legs): a chunk is read when its box touches the
+                // bounding sphere of a leg that is still searching (empty chunks carry an inverted box)
+                uint32_t cnear = 0u;
+                {
+                    const float* cb = boxes + (ntiles + tile * 16 + (lane & 15)) * 6;
+                    for (int l0 = 0; l0 < nlegs; l0 += 4) { // wave-uniform
+                        const int l = l0 + (lane >> 4);
+                        bool touch = false;
+                        if (l < nlegs && !((found >> l) & 1u))
+                            touch = box_dist2(cb, body.x + s_sphere[l][0], body.y + s_sphere[l][1], body.z + s_sphere[l][2]) * 0.999f <=
+                                    s_sphere[l][3];
+                        const unsigned long long mm = __ballot(touch);
+                        cnear |= (uint32_t)((mm | (mm >> 16) | (mm >> 32) | (mm >> 48)) & 0xffffull);
+                    }
+                }
                 // software pipeline: the next near chunk's loads are issued before this one is tested
                 LrmVec3 nxt{0.f, 0.f, 0.f};
                 bool nxt_ok = false;
