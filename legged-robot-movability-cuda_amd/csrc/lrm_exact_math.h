@@ -162,7 +162,6 @@ LRM_HD void lrm_sincosf(float y, float* sinp, float* cosp) {
     const uint32_t top = (lrm_f2u(y) >> 20) & 0x7ff;
     double x = (double)y;
     int n = 0;
-    double csign = 1.0; // table 1 of the original negates the cosine polynomial
     if (top < 0x3f4u) { // |y| < pi/4
         if (top < 0x398u) { // |y| < 2^-12
             *sinp = y;
@@ -174,7 +173,6 @@ LRM_HD void lrm_sincosf(float y, float* sinp, float* cosp) {
         n = ((int32_t)r + 0x800000) >> 24;
         x = __builtin_fma(-(double)n, hpi, x);
         const double s = ((n + 1) & 2) ? -1.0 : 1.0; // sign[] = {1,-1,-1,1}
-        if (n & 2) csign = -1.0;
         x = x * s;
     } else {
         // |y| >= 120, inf, nan: outside the emulated range (the path only produces angles in
@@ -186,15 +184,18 @@ LRM_HD void lrm_sincosf(float y, float* sinp, float* cosp) {
     const double x2 = x * x;
     const double x4 = x2 * x2;
     const double x3 = x2 * x;
-    const double c2 = __builtin_fma(x2, csign * C4, csign * C3);
+    // For n & 2 the original switches to a second coefficient table whose C0..C4 are negated: every
+    // operation of the cosine polynomial then yields the exact negative (IEEE rounding is symmetric
+    // in sign), so the polynomial runs once with the positive table and the float result changes sign.
+    const double c2 = __builtin_fma(x2, C4, C3);
     const double s1 = __builtin_fma(x2, S3, S2);
-    const double c1 = __builtin_fma(x2, csign * C1, csign * C0);
+    const double c1 = __builtin_fma(x2, C1, C0);
     const double x5 = x3 * x2;
     const double x6 = x4 * x2;
     const double s = __builtin_fma(x3, S1, x);
-    const double c = __builtin_fma(x4, csign * C2, c1);
+    const double c = __builtin_fma(x4, C2, c1);
     const float sv = (float)__builtin_fma(x5, s1, s);
-    const float cv = (float)__builtin_fma(x6, c2, c);
+    const float cv = lrm_u2f(lrm_f2u((float)__builtin_fma(x6, c2, c)) ^ (((uint32_t)n & 2u) << 30));
     if (n & 1) { *sinp = cv; *cosp = sv; }
     else { *sinp = sv; *cosp = cv; }
 }
