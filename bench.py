@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000, help="targets per GPU")
     ap.add_argument("--mode", choices=["strict", "fast"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precondition-ms", type=float, default=150.0,
+    ap.add_argument("--precondition-ms", type=float, default=100.0,
                     help="untimed GPU load before the W warm-up steps so that short runs are also measured at the "
                          "steady clocks (the first ~50 ms after idle run ~15 %% slower); 0 disables it")
     args = ap.parse_args()
@@ -181,6 +181,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    import gc
+    gc.collect()
+    gc.disable()  # a generation-2 collection inside the timed loop costs tens of ms of launch-queue starvation
     if args.precondition_ms > 0:  # clock conditioning: the same launch, results discarded, before the warm-up
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
@@ -198,6 +201,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = reduce_max(elapsed)
+    gc.enable()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     # secondary figures (not part of the timed region): reach-only and distance-only kernels
