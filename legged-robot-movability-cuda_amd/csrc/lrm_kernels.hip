@@ -54,8 +54,11 @@ static_assert(kLegArgSoA == 32 && kLegArgAoS == 16, "kernarg layout");
 #ifndef LRM_DIST_GRID_MULT
 #define LRM_DIST_GRID_MULT 8 // workgroups launched per resident workgroup (see lrm_launch_dist_soa): 4 / 8 / 16 / 32 -> 0.220 / 0.216 / 0.218 / 0.223 ms
 #endif
+#ifndef LRM_REACH_GRID
+#define LRM_REACH_GRID (256 * 32) // workgroups at most: 2048 / 8192 / 16384 / one quad per lane -> 27.0 / 24.4 / 25.3 / 25.3 us at 1e7 points
+#endif
 #ifndef LRM_REACH_MIN_WAVES
-#define LRM_REACH_MIN_WAVES 1
+#define LRM_REACH_MIN_WAVES 8 // 64 VGPRs, no scratch: 24.4 us at 1e7 points against 26.0 at the compiler's choice (75 VGPRs, 6 waves)
 #endif
 
 // LDS image of the per-lane-indexed tables: circle lists, filter records, corner points (~2 KB)
@@ -109,7 +112,11 @@ __device__ __forceinline__ bool eval_pair(const LrmCompiledLeg& L, const LdsTabl
 
 // ------------------------------------------------------------------------------------
 // reachability_global_kernel (one_leg_global.cu:149-156), 4 consecutive points per lane:
-// three 16-byte loads in, one 4-byte store out.
+// three 16-byte loads in, one 4-byte store out; in the filtered mode the (rare) doubtful points are
+// re-evaluated by the strict code in the same launch, the bit words come from a 16-lane shuffle.
+// (A two-launch variant -- filter only, then a fix-up pass over the mask -- was the faster one
+// while the strict code in the loop cost SGPR spills and occupancy; since the leg is read through
+// the kernarg pointer this single pass at 8 waves/SIMD takes 24.4 us at 1e7 points against 30.0.)
 // ------------------------------------------------------------------------------------
 template <bool kBits, bool kFast>
 __global__ __launch_bounds__(kBlock, LRM_REACH_MIN_WAVES) void reach_soa_kernel(const float* __restrict__ x,
@@ -187,97 +194,6 @@ __global__ __launch_bounds__(kBlock, LRM_REACH_MIN_WAVES) void reach_soa_kernel(
         for (size_t i = w0; i < n; i++)
             w |= (uint64_t)eval_reach<kFast>(L, &s_tab, LrmVec3{x[i], y[i], z[i]}) << (i - w0);
         bits[w0 >> 6] = w;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// Filtered reachability in two launches (the library default for aligned SoA input):
-//   pass 1  reach_lean_kernel   the lean filter only (lrm_point_fast.h), ~70 VALU instructions per
-//           point, no strict code in the kernel (keeping it out is worth 25 % of the hot loop):
-//           mask byte = answer | 2 * uncertain.
-//   pass 2  reach_fixup_kernel  re-reads the mask (1 B/point, 16 points per lane), re-evaluates the
-//           flagged points with the strict code, and builds the ballot-layout bit words from the
-//           final bytes.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void reach_lean_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                            const float* __restrict__ z, size_t n,
-                                                            const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask) {
-    __shared__ LrmCompiledLeg::LeanCircle s_lean[16];
-    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kLegArgSoA);
-    if (threadIdx.x < 64) reinterpret_cast<float*>(s_lean)[threadIdx.x] = reinterpret_cast<const float*>(&L.lean[0][0])[threadIdx.x];
-    __syncthreads();
-    const size_t nquad = n >> 2;
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t qd = (size_t)blockIdx.x * kBlock + threadIdx.x; qd < nquad; qd += stride) {
-        const float4 vx = reinterpret_cast<const float4*>(x)[qd];
-        const float4 vy = reinterpret_cast<const float4*>(y)[qd];
-        const float4 vz = reinterpret_cast<const float4*>(z)[qd];
-        uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0;
-        const uint32_t r0 = lrm_reach_global_fast(L, s_lean, LrmVec3{vx.x, vy.x, vz.x}, u0);
-        const uint32_t r1 = lrm_reach_global_fast(L, s_lean, LrmVec3{vx.y, vy.y, vz.y}, u1);
-        const uint32_t r2 = lrm_reach_global_fast(L, s_lean, LrmVec3{vx.z, vy.z, vz.z}, u2);
-        const uint32_t r3 = lrm_reach_global_fast(L, s_lean, LrmVec3{vx.w, vy.w, vz.w}, u3);
-        reinterpret_cast<uint32_t*>(mask)[qd] = (r0 | (u0 << 1)) | ((r1 | (u1 << 1)) << 8) | ((r2 | (u2 << 1)) << 16) |
-                                                ((r3 | (u3 << 1)) << 24);
-    }
-    // the n % 4 last points: flag them all, pass 2 evaluates them
-    const size_t tail0 = nquad << 2;
-    if (blockIdx.x == 0 && tail0 + threadIdx.x < n) mask[tail0 + threadIdx.x] = 2;
-}
-
-template <bool kBits>
-__global__ __launch_bounds__(kBlock) void reach_fixup_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                             const float* __restrict__ z, size_t n,
-                                                             const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask,
-                                                             uint64_t* __restrict__ bits) {
-    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kLegArgSoA);
-    // One lane owns 16 consecutive points (one coalesced 16-byte mask load), four lanes one bit
-    // word.  No LDS: the rare strict re-evaluation reads the circle lists from the kernel argument
-    // segment directly.
-    const LrmCircle* lists = &L.lists[0][0];
-    const size_t ngroup = (n >> 6) << 2; // whole 64-point words only; the rest is the tail below
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < ngroup; g += stride) {
-        const uint4 m = reinterpret_cast<const uint4*>(mask)[g];
-        uint32_t redone = 0, redone_val = 0; // bits patched by the strict re-evaluation
-        if (__builtin_expect(((m.x | m.y | m.z | m.w) & 0x02020202u) != 0u, 0)) {
-#pragma unroll 1
-            for (int b = 0; b < 16; b++) {
-                const size_t i = (g << 4) + b;
-                const uint32_t wsel = (b < 4) ? m.x : (b < 8) ? m.y : (b < 12) ? m.z : m.w; // registers only
-                if (!((wsel >> (8 * (b & 3))) & 2u)) continue;
-                const uint32_t r = lrm_reach_global(L, lists, LrmVec3{x[i], y[i], z[i]}) ? 1u : 0u;
-                mask[i] = (uint8_t)r;
-                redone |= 1u << b;
-                redone_val |= r << b;
-            }
-        }
-        if (kBits) {
-            // (v & 0x01010101) * 0x10204081 gathers bit 0 of the four bytes at bits 21..24
-            auto nib = [](uint32_t v) { return (((v & 0x01010101u) * 0x10204081u) >> 21) & 0xfu; };
-            uint32_t part = nib(m.x) | (nib(m.y) << 4) | (nib(m.z) << 8) | (nib(m.w) << 12);
-            part = (part & ~redone) | redone_val;
-            // 4 lanes -> one 64-bit word (lanes of a quad: DPP quad_perm moves)
-            const uint32_t p1 = __shfl_xor(part, 1);
-            const uint32_t lo = (threadIdx.x & 1) ? (p1 | (part << 16)) : (part | (p1 << 16));
-            const uint32_t hi = __shfl_xor(lo, 2);
-            if ((threadIdx.x & 3) == 0) bits[g >> 2] = (uint64_t)lo | ((uint64_t)hi << 32);
-        }
-    }
-    // points [64 * (n / 64), n): the first wave of block 0, one point per lane, ballot = bit word
-    const size_t n64 = (n >> 6) << 6;
-    if (blockIdx.x == 0 && threadIdx.x < 64 && n64 < n) {
-        const size_t i = n64 + threadIdx.x;
-        uint32_t b = 0;
-        if (i < n) {
-            b = mask[i];
-            if (b & 2u) {
-                b = lrm_reach_global(L, lists, LrmVec3{x[i], y[i], z[i]}) ? 1u : 0u;
-                mask[i] = (uint8_t)b;
-            }
-        }
-        const uint64_t wv = __ballot((b & 1u) != 0u);
-        if (kBits && threadIdx.x == 0) bits[n64 >> 6] = wv;
     }
 }
 
@@ -987,24 +903,12 @@ hipError_t lrm_launch_reach_soa(const float* x, const float* y, const float* z, 
                                 const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, bool fast, hipStream_t st) {
     fast = fast && L.fast_ok;
     const uintptr_t align = (uintptr_t)x | (uintptr_t)y | (uintptr_t)z;
-    // two launches pay off once the cloud is large; small clouds are launch-latency bound
-    if (fast && mask && n >= ((size_t)1 << 20) && !(align & 15) && !((uintptr_t)mask & 15)) {
-        // grid sweep at 1e7 points (lean x fix-up workgroups): 2048 x 2048 -> 36.9 us, 8192 x 2442 (one
-        // 16-point group per lane, no grid-stride loop) -> 32.2 us
-        hipLaunchKernelGGL(reach_lean_kernel, dim3(grid_for((n + 3) / 4, 256 * 32)), dim3(kBlock), 0, st, x, y, z, n, L, mask);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        const int g2 = grid_for((n + 15) / 16, 256 * 256);
-        if (bits) hipLaunchKernelGGL(reach_fixup_kernel<true>, dim3(g2), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
-        else hipLaunchKernelGGL(reach_fixup_kernel<false>, dim3(g2), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
-        return hipGetLastError();
-    }
     if ((align & 15) || ((uintptr_t)mask & 3)) {
         if (fast) hipLaunchKernelGGL(reach_soa_scalar_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
         else hipLaunchKernelGGL(reach_soa_scalar_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
         return hipGetLastError();
     }
-    const int grid = grid_for((n + 3) / 4);
+    const int grid = grid_for((n + 3) / 4, LRM_REACH_GRID);
     if (bits && fast) hipLaunchKernelGGL((reach_soa_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
     else if (bits) hipLaunchKernelGGL((reach_soa_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);
     else if (fast) hipLaunchKernelGGL((reach_soa_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, x, y, z, n, L, mask, bits);

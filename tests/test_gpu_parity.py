@@ -64,7 +64,7 @@ def test_device_api_matches_reference_fixture(lrm, torch_cuda, name):
     assert np.array_equal(bits.cpu().numpy().view(np.uint64), packed)
 
 
-# sizes >= 2^20 take the two-launch reach path (lean pass + fix-up/bit-pack pass)
+# sizes around 2^20: several grid-stride iterations, quads and tails of the single-launch reach kernel
 @pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 4099, 100003,
                                1048576, 1048577, 1048579, 1048639, 1048641])
 def test_ragged_sizes(lrm, oracle, torch_cuda, n):
