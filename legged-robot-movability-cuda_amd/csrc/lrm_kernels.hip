@@ -171,13 +171,15 @@ __global__ __launch_bounds__(kBlock, LRM_REACH_MIN_WAVES) void reach_soa_kernel(
         if (kBits) {
             // 16 lanes x 4 points = one 64-bit word
             const uint32_t nib = (packed & 1u) | ((packed >> 7) & 2u) | ((packed >> 14) & 4u) | ((packed >> 21) & 8u);
+            // lanes 0-7 of a 16-lane group make the low half of the word, lanes 8-15 the high half:
+            // three 32-bit exchanges inside the 8-lane groups, one across
             const int sub = threadIdx.x & 15;
-            uint64_t w = (uint64_t)nib << (4 * sub);
-            w |= __shfl_xor(w, 1);
-            w |= __shfl_xor(w, 2);
-            w |= __shfl_xor(w, 4);
-            w |= __shfl_xor(w, 8);
-            if (sub == 0 && (qd >> 4) < (n >> 6)) bits[qd >> 4] = w; // full words only
+            uint32_t h = nib << (4 * (sub & 7));
+            h |= __shfl_xor(h, 1);
+            h |= __shfl_xor(h, 2);
+            h |= __shfl_xor(h, 4);
+            const uint32_t hi = __shfl_down(h, 8);
+            if (sub == 0 && (qd >> 4) < (n >> 6)) bits[qd >> 4] = (uint64_t)h | ((uint64_t)hi << 32); // full words only
         }
     }
     // tail: n % 4 points, handled by the first lanes of block 0
