@@ -170,7 +170,8 @@ __global__ __launch_bounds__(kBlock, LRM_REACH_MIN_WAVES) void reach_soa_kernel(
         }
         if (kBits) {
             // 16 lanes x 4 points = one 64-bit word
-            const uint32_t nib = (packed & 1u) | ((packed >> 7) & 2u) | ((packed >> 14) & 4u) | ((packed >> 21) & 8u);
+            // bit 0 of the four mask bytes gathered at bits 21..24 by one multiplication
+            const uint32_t nib = (((packed & 0x01010101u) * 0x10204081u) >> 21) & 0xfu;
             // lanes 0-7 of a 16-lane group make the low half of the word, lanes 8-15 the high half:
             // three 32-bit exchanges inside the 8-lane groups, one across
             const int sub = threadIdx.x & 15;
