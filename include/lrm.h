@@ -44,6 +44,15 @@ extern "C" {
  *                  Legs outside the filter's eligibility silently use the strict kernels. */
 #define LRM_MODE_STRICT 0
 #define LRM_MODE_FAST 1
+/* LRM_MODE_TOL:    BASELINE contract tolerance (csrc/lrm_point_tol.h): the reach mask and the distance's
+ *                  validity byte stay bit-identical to LRM_MODE_STRICT; the distance VECTOR is computed with
+ *                  FP32 FMA / v_rsq_f32 arithmetic (no atan2f / sincosf / IEEE sqrt) and lands on the same
+ *                  boundary feature as the reference's: |d - d_ref| <= 1e-5 max(|d_ref|, |p| / 16) per point
+ *                  (a few ulp of the coordinates; tests/test_gpu_tol.py).  Points with any decision inside its
+ *                  error band are re-evaluated by the LRM_MODE_FAST code in a second small launch and are
+ *                  bit-identical.  Applies to the distance / fused entry points; reach-only and pair kernels
+ *                  run as in LRM_MODE_FAST.  Legs outside the mode's eligibility use LRM_MODE_FAST. */
+#define LRM_MODE_TOL 2
 
 /* LegDimensions, HeaderCPP.h:19-52: 14 x f32 = 56 bytes, this field order. */
 typedef struct LrmLegDimensions {
@@ -233,6 +242,13 @@ int lrm_dbg_sqrt_check_dev(uint64_t* mismatches_out, uint32_t* first_bad_out);
 int lrm_dbg_fast_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                       uint8_t* mask_out, uint8_t* mask_uncertain_out, float* dxyz_aos_out,
                       uint8_t* valid_out, uint8_t* dist_uncertain_out);
+/* The contract-tolerance evaluation (LRM_MODE_TOL, csrc/lrm_point_tol.h) on the host WITHOUT the bit-exact
+ * re-evaluation of its doubtful points: mask_out = reach / validity flag, doubt_out = LRM_TD_* bits (0: the
+ * outputs are final).  Fails with LRM_EINVAL for a leg the mode does not support. */
+int lrm_dbg_tol_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+                     uint8_t* mask_out, float* dxyz_aos_out, uint32_t* doubt_out);
+/* 1 if (leg, quat) is eligible for LRM_MODE_TOL, else 0 */
+int lrm_dbg_tol_ok(const LrmLegDimensions* leg, const float* quat);
 /* The per-leg bounding sphere the pair kernels use to skip batches of footholds:
  * out4 = {cx, cy, cz (relative to the body position), squared radius}.  Tests check that every
  * pair the strict reachable_rotate_leg accepts lies inside. */

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LRM_LIB_PATH: load another build of the same library (A/B runs of kernel variants)
 LIB_PATH = os.environ.get("LRM_LIB_PATH") or os.path.join(_HERE, "liblrm.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lrm.h")
-MODE_STRICT, MODE_FAST = 0, 1
+MODE_STRICT, MODE_FAST, MODE_TOL = 0, 1, 2
 _lib = None
 
 
@@ -78,6 +78,8 @@ def load():
         "lrm_morton_order": [vp, sz, vp],
         "lrm_dbg_fast_host": [vp, sz, vp, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_fused_reach_host": [vp, sz, vp, vp, vp, vp],
+        "lrm_dbg_tol_host": [vp, sz, vp, vp, vp, vp, vp],
+        "lrm_dbg_tol_ok": [vp, vp],
         "lrm_dbg_pair_sphere": [vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
         "lrm_dbg_exact_math_dev": [vp, vp, sz, vp, vp, vp, vp],
@@ -278,6 +280,20 @@ def dbg_fast_host(xyz, leg, quat=None):
                                    _ptr(out["mask_unc"]), _ptr(out["dist"]), _ptr(out["valid"]),
                                    _ptr(out["dist_unc"])))
     return out
+
+
+def dbg_tol_host(xyz, leg, quat=None):
+    """Contract-tolerance evaluation on the host, no re-evaluation -> (mask, dist, doubt bits uint32)."""
+    xyz = _f32(xyz, (-1, 3))
+    n = len(xyz)
+    mask, d, doubt = np.zeros(n, np.uint8), np.zeros_like(xyz), np.zeros(n, np.uint32)
+    check(load().lrm_dbg_tol_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d),
+                                  _ptr(doubt)))
+    return mask, d, doubt
+
+
+def dbg_tol_ok(leg, quat=None):
+    return bool(load().lrm_dbg_tol_ok(_ptr(_f32(leg, (14,))), _ptr(_quat(quat))))
 
 
 def dbg_pair_sphere(leg, quat=None):

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -12,6 +13,7 @@
 #include "lrm_launch.h"
 #include "lrm_point.h"
 #include "lrm_point_fast.h"
+#include "lrm_point_tol.h"
 
 namespace {
 
@@ -34,6 +36,78 @@ int hip_fail(hipError_t e, const char* where) {
     } while (0)
 
 const float* quat_or_default(const float* q) { return q ? q : kQuatTest; }
+
+// ---- LRM_MODE_TOL plumbing ---------------------------------------------------------------------
+// The tolerance block of a (leg, quaternion) costs a few hundred microseconds of host geometry (arc
+// intersections + their verification, lrm_compile_tol): a small cache keyed by the 18 input floats.
+struct TolKey {
+    float v[18];
+    bool operator<(const TolKey& o) const { return std::memcmp(v, o.v, sizeof v) < 0; }
+};
+std::map<TolKey, LrmTolLeg> g_tol_cache;
+const LrmTolLeg& tol_leg(const LrmLegDimensions& leg, const float* quat, const LrmCompiledLeg& L) {
+    TolKey k;
+    std::memcpy(k.v, &leg, 14 * sizeof(float));
+    std::memcpy(k.v + 14, quat, 4 * sizeof(float));
+    auto it = g_tol_cache.find(k);
+    if (it != g_tol_cache.end()) return it->second;
+    if (g_tol_cache.size() >= 64) g_tol_cache.clear();
+    LrmTolLeg t;
+    lrm_compile_tol(L, &t);
+    return g_tol_cache.emplace(k, t).first->second;
+}
+// Device workspace of the doubt queue, one per (device, stream) in use: queue[cap] + {length, blocks done}.
+struct TolWorkspace {
+    uint32_t* queue = nullptr;
+    uint32_t* counters = nullptr;
+    size_t cap = 0;
+};
+std::map<std::pair<int, void*>, TolWorkspace> g_tol_ws;
+int tol_workspace(size_t n, void* stream, TolWorkspace** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+    TolWorkspace& w = g_tol_ws[std::make_pair(dev, stream)];
+    const size_t need = std::max<size_t>(n / 8, 4096); // more than 1/8 of the cloud in doubt: the fix-up redoes everything
+    if (!w.counters) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, 2 * sizeof(uint32_t)), "hipMalloc tol counters");
+        w.counters = static_cast<uint32_t*>(p);
+        HIP_TRY(hipMemset(w.counters, 0, 2 * sizeof(uint32_t)), "hipMemset tol counters");
+    }
+    if (need > w.cap) {
+        if (w.queue) (void)hipFree(w.queue); // synchronises with whatever still reads it
+        w.queue = nullptr;
+        w.cap = 0;
+        void* p = nullptr;
+        const size_t cap = need + need / 2;
+        HIP_TRY(hipMalloc(&p, cap * sizeof(uint32_t)), "hipMalloc tol queue");
+        w.queue = static_cast<uint32_t*>(p);
+        w.cap = cap;
+    }
+    *out = &w;
+    return LRM_OK;
+}
+
+// distance / fused launch of the SoA kernels in the current mode. op: 1 distance, 2 reach + distance
+int launch_dist_mode(int op, const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions& leg,
+                     const float* quat, const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
+                     float* dz, void* stream) {
+    if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xffffffffull) {
+        const LrmTolLeg& TL = tol_leg(leg, quat, L);
+        if (TL.tol_ok) {
+            TolWorkspace* w = nullptr;
+            const int rc = tol_workspace(n, stream, &w);
+            if (rc != LRM_OK) return rc;
+            HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w->queue,
+                                        (uint32_t)std::min<size_t>(w->cap, 0xffffffffull), w->counters, (hipStream_t)stream),
+                    "tolerance-mode launch");
+            return LRM_OK;
+        }
+    }
+    HIP_TRY(lrm_launch_dist_soa(op, x, y, z, n, L, mask, bits, dx, dy, dz, g_mode != LRM_MODE_STRICT, (hipStream_t)stream),
+            "distance launch");
+    return LRM_OK;
+}
 
 // RAII device buffer for the host-buffer entry points
 struct DevBuf {
@@ -76,9 +150,9 @@ int host_apply(int op, const float* xyz, size_t n, const LrmLegDimensions* leg, 
     HIP_TRY(hipEventCreate(&ev.b), "hipEventCreate");
     HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
     if (n) {
-        if (op == 0) HIP_TRY(lrm_launch_reach_aos(d_in.as<float>(), n, L, d_mask.as<uint8_t>(), g_mode == LRM_MODE_FAST, nullptr), "Kernel launch");
+        if (op == 0) HIP_TRY(lrm_launch_reach_aos(d_in.as<float>(), n, L, d_mask.as<uint8_t>(), g_mode != LRM_MODE_STRICT, nullptr), "Kernel launch");
         else HIP_TRY(lrm_launch_dist_aos(op, d_in.as<float>(), n, L, want_mask ? d_mask.as<uint8_t>() : nullptr,
-                                         d_out.as<float>(), g_mode == LRM_MODE_FAST, nullptr), "Kernel launch");
+                                         d_out.as<float>(), g_mode != LRM_MODE_STRICT, nullptr), "Kernel launch");
     }
     HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
     HIP_TRY(hipEventSynchronize(ev.b), "Kernel launch");
@@ -165,7 +239,7 @@ int lrm_set_device(int ordinal) {
     return LRM_OK;
 }
 int lrm_set_mode(int mode) {
-    if (mode != LRM_MODE_STRICT && mode != LRM_MODE_FAST) return fail(LRM_EINVAL, "unknown mode");
+    if (mode != LRM_MODE_STRICT && mode != LRM_MODE_FAST && mode != LRM_MODE_TOL) return fail(LRM_EINVAL, "unknown mode");
     g_mode = mode;
     return LRM_OK;
 }
@@ -229,11 +303,14 @@ int host_apply_soa(int op, const float* x, const float* y, const float* z, size_
     HIP_TRY(hipEventCreate(&ev.a), "hipEventCreate");
     HIP_TRY(hipEventCreate(&ev.b), "hipEventCreate");
     HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
-    const bool fast = g_mode == LRM_MODE_FAST;
+    const bool fast = g_mode != LRM_MODE_STRICT;
     float* O = d_out.as<float>();
     if (op == 0) HIP_TRY(lrm_launch_reach_soa(I, I + pad, I + 2 * pad, n, L, d_mask.as<uint8_t>(), nullptr, fast, nullptr), "Kernel launch");
-    else HIP_TRY(lrm_launch_dist_soa(op, I, I + pad, I + 2 * pad, n, L, want_mask ? d_mask.as<uint8_t>() : nullptr, nullptr, O,
-                                     O + pad, O + 2 * pad, fast, nullptr), "Kernel launch");
+    else {
+        const int rc = launch_dist_mode(op, I, I + pad, I + 2 * pad, n, *leg, quat_or_default(quat), L,
+                                        want_mask ? d_mask.as<uint8_t>() : nullptr, nullptr, O, O + pad, O + 2 * pad, nullptr);
+        if (rc != LRM_OK) return rc;
+    }
     HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
     HIP_TRY(hipEventSynchronize(ev.b), "Kernel launch");
     float elapsed = 0.f;
@@ -297,7 +374,7 @@ int lrm_reach_bits_dev(const float* x, const float* y, const float* z, size_t n,
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_reach_soa(x, y, z, n, L, mask, bits, g_mode == LRM_MODE_FAST, (hipStream_t)stream), "reach launch");
+    HIP_TRY(lrm_launch_reach_soa(x, y, z, n, L, mask, bits, g_mode != LRM_MODE_STRICT, (hipStream_t)stream), "reach launch");
     return LRM_OK;
 }
 int lrm_reach_dev(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
@@ -310,8 +387,7 @@ int lrm_dist_dev(const float* x, const float* y, const float* z, size_t n, const
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_dist_soa(1, x, y, z, n, L, valid, nullptr, dx, dy, dz, g_mode == LRM_MODE_FAST, (hipStream_t)stream), "dist launch");
-    return LRM_OK;
+    return launch_dist_mode(1, x, y, z, n, *leg, quat_or_default(quat), L, valid, nullptr, dx, dy, dz, stream);
 }
 int lrm_reach_dist_bits_dev(const float* x, const float* y, const float* z, size_t n,
                             const LrmLegDimensions* leg, const float* quat, uint8_t* mask, uint64_t* bits,
@@ -321,8 +397,7 @@ int lrm_reach_dist_bits_dev(const float* x, const float* y, const float* z, size
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_dist_soa(2, x, y, z, n, L, mask, bits, dx, dy, dz, g_mode == LRM_MODE_FAST, (hipStream_t)stream), "reach+dist launch");
-    return LRM_OK;
+    return launch_dist_mode(2, x, y, z, n, *leg, quat_or_default(quat), L, mask, bits, dx, dy, dz, stream);
 }
 int lrm_reach_dist_dev(const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions* leg,
                        const float* quat, uint8_t* mask, float* dx, float* dy, float* dz, void* stream) {
@@ -335,7 +410,7 @@ int lrm_reach_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, c
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_reach_aos(xyz, n, L, mask, g_mode == LRM_MODE_FAST, (hipStream_t)stream), "reach launch");
+    HIP_TRY(lrm_launch_reach_aos(xyz, n, L, mask, g_mode != LRM_MODE_STRICT, (hipStream_t)stream), "reach launch");
     return LRM_OK;
 }
 int lrm_dist_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, float* dxyz,
@@ -344,7 +419,7 @@ int lrm_dist_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, co
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_dist_aos(1, xyz, n, L, valid, dxyz, g_mode == LRM_MODE_FAST, (hipStream_t)stream), "dist launch");
+    HIP_TRY(lrm_launch_dist_aos(1, xyz, n, L, valid, dxyz, g_mode != LRM_MODE_STRICT, (hipStream_t)stream), "dist launch");
     return LRM_OK;
 }
 
@@ -426,7 +501,7 @@ int reach_any_impl(const float* bx, const float* by, const float* bz, size_t nb,
     HIP_TRY(hipMemcpyAsync(dev_legs, host_legs, sizeof(LrmCompiledLeg) * nlegs, hipMemcpyHostToDevice,
                            (hipStream_t)stream), "hipMemcpyAsync legs");
     // pageable-source async copies are staged by the runtime before returning, so host_legs may die
-    bool fast = g_mode == LRM_MODE_FAST;
+    bool fast = g_mode != LRM_MODE_STRICT;
     for (size_t l = 0; l < nlegs; l++) fast = fast && host_legs[l].fast_ok;
     float* boxes = nullptr;
     if (nt >= 4096) { // below that the whole cloud is a handful of tiles: nothing to skip
@@ -567,6 +642,36 @@ int lrm_dbg_fast_host(const float* xyz, size_t n, const LrmLegDimensions* leg, c
         }
     }
     return LRM_OK;
+}
+
+// The contract-tolerance evaluation on the host, WITHOUT the re-evaluation of its doubtful points.
+int lrm_dbg_tol_host(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
+                     float* dxyz_out, uint32_t* doubt_out) {
+    if (!leg || (n && (!xyz || !mask_out || !dxyz_out || !doubt_out))) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    LrmTolLeg TL;
+    lrm_compile_tol(L, &TL);
+    if (!TL.tol_ok) return fail(LRM_EINVAL, "leg not eligible for the tolerance mode");
+    const LrmTolTables T{&TL.circ[0][0], &TL.feat[0]};
+    for (size_t i = 0; i < n; i++) {
+        LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        uint32_t doubt = 0;
+        mask_out[i] = lrm_dist_tol(TL, T, p, doubt);
+        dxyz_out[3 * i] = p.x;
+        dxyz_out[3 * i + 1] = p.y;
+        dxyz_out[3 * i + 2] = p.z;
+        doubt_out[i] = doubt;
+    }
+    return LRM_OK;
+}
+int lrm_dbg_tol_ok(const LrmLegDimensions* leg, const float* quat) {
+    if (!leg) return 0;
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    LrmTolLeg TL;
+    lrm_compile_tol(L, &TL);
+    return TL.tol_ok;
 }
 
 // robot_full_struct's pipeline (several_leg.cu:326-877) with masks instead of thrust stream

@@ -11,6 +11,8 @@
 #include "lrm_point_fast.h" // LRM_BAND, LRM_BAND_DIST
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -392,4 +394,252 @@ void lrm_compile_leg(const LrmLegDimensions& leg_in, const float quat[4], int ap
     // circle test, so pairs beyond this radius are skipped without changing any result.
     const float reach = l.body + l.coxa_length + l.femur_length + l.tibia_length + 1.0f;
     out->reach_r2_max = reach * reach * 1.0001f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tolerance mode tables (lrm_point_tol.h)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// Signed distance (mm) of the clamp point of circle i at direction `th` to the validity boundary
+// of the other three circles of its list: max_j sg_j (|q - c_j| - thr_j), q = c_i + r_i (cos th, sin th);
+// the clamp point passes multi_circle_validate (one_leg.cu:65-89) <=> the value is negative
+// (it is always valid for its own circle: |d| ~ 0 < CIRCLE_MARGIN).
+double clamp_validity(const LrmCircle* list, int i, double th) {
+    const double margin = 0.001;
+    const double qx = (double)list[i].x + (double)list[i].r * std::cos(th);
+    const double qy = (double)list[i].y + (double)list[i].r * std::sin(th);
+    double g = -1e300;
+    for (int j = 0; j < LRM_N_CIRCLES; j++) {
+        if (j == i) continue;
+        const bool attract = list[j].attract != 0.f;
+        const double thr = attract ? (double)list[j].r + margin : (double)list[j].r - margin;
+        const double mag = std::hypot(qx - (double)list[j].x, qy - (double)list[j].y);
+        g = std::max(g, attract ? mag - thr : thr - mag);
+    }
+    return g;
+}
+
+// The directions for which the clamp point of circle i is valid, as ONE arc {u : u . m >= chw} when that is
+// what the set is.  eps (mm): how far the reference's float clamp point and its float validation can be from
+// the exact ones; directions whose clamp point is within eps of a validity boundary get a doubt band `bw` on
+// w = u . m - chw.  Returns false when the set is not a single arc (or empty / everything) or when a
+// boundary is approached without being crossed (grazing circles).
+#define TOL_REJECT(why)                                                                               \
+    do {                                                                                              \
+        if (std::getenv("LRM_TOL_DEBUG")) std::fprintf(stderr, "lrm_compile_tol: circle %d: %s\n", i, why); \
+        return false;                                                                                 \
+    } while (0)
+// [qa, qb] (qa <= qb, radians, qb - qa >= 2 pi: everything): the only directions the per-point code can ask
+// about -- for a circle centred on the femur joint the clamp direction is the direction of the point itself,
+// which find_region confines to the region's sector.
+bool clamp_arc(const LrmCircle* list, int i, double eps, double qa, double qb, LrmTolLeg::Circle* out) {
+    const double two_pi = 6.283185307179586;
+    const bool everything = (qb - qa) >= two_pi;
+    auto in_query = [&](double th) { // th in any branch
+        if (everything) return true;
+        double t = std::fmod(th - qa, two_pi);
+        if (t < 0) t += two_pi;
+        return t <= (qb - qa);
+    };
+    const double margin = 0.001;
+    const double ri = list[i].r;
+    double cand[2 * LRM_N_CIRCLES];
+    int nc = 0;
+    for (int j = 0; j < LRM_N_CIRCLES; j++) {
+        if (j == i) continue;
+        const double ex = (double)list[i].x - (double)list[j].x, ey = (double)list[i].y - (double)list[j].y;
+        const double E = std::hypot(ex, ey);
+        if (!(E > 0)) continue; // concentric: the validity does not depend on the direction
+        const double thr = (list[j].attract != 0.f) ? (double)list[j].r + margin : (double)list[j].r - margin;
+        const double kappa = (thr * thr - E * E - ri * ri) / (2.0 * ri * E);
+        if (!(std::fabs(kappa) < 1.0)) continue;
+        const double phi = std::atan2(ey, ex), a = std::acos(kappa);
+        cand[nc++] = std::fmod(phi + a + 2 * two_pi, two_pi);
+        cand[nc++] = std::fmod(phi - a + 2 * two_pi, two_pi);
+    }
+    std::sort(cand, cand + nc);
+    // valid / invalid on the elementary intervals between consecutive candidates
+    double arc_a = 0, arc_b = 0;
+    int n_arcs = 0;
+    bool all_valid = false;
+    if (nc == 0) {
+        all_valid = clamp_validity(list, i, 0.0) < 0;
+    } else {
+        bool val[2 * LRM_N_CIRCLES];
+        for (int k = 0; k < nc; k++) {
+            const double lo = cand[k], hi = (k + 1 < nc) ? cand[k + 1] : cand[0] + two_pi;
+            val[k] = clamp_validity(list, i, 0.5 * (lo + hi)) < 0;
+        }
+        bool any = false, every = true;
+        for (int k = 0; k < nc; k++) { any = any || val[k]; every = every && val[k]; }
+        if (every) all_valid = true;
+        else if (any) {
+            // arcs = maximal cyclic runs of valid intervals
+            for (int k = 0; k < nc; k++) {
+                const int prev = (k + nc - 1) % nc;
+                if (val[k] && !val[prev]) { // a run starts at cand[k]
+                    int e = k;
+                    while (val[(e + 1) % nc] && (e + 1 - k) < nc) e++;
+                    const double a0 = cand[k];
+                    double b0 = cand[(e + 1) % nc];
+                    if (b0 <= a0) b0 += two_pi;
+                    bool hit = everything;
+                    if (!hit) { // does [a0, b0] meet [qa, qb] (mod 2 pi)?  Either holds an end of the other.
+                        double t = std::fmod(a0 - qa, two_pi);
+                        if (t < 0) t += two_pi;
+                        hit = t <= (qb - qa);
+                        t = std::fmod(qa - a0, two_pi);
+                        if (t < 0) t += two_pi;
+                        hit = hit || t <= (b0 - a0);
+                    }
+                    if (!hit) continue;
+                    n_arcs++;
+                    arc_a = a0;
+                    arc_b = b0;
+                }
+            }
+        }
+    }
+    if (std::getenv("LRM_TOL_DEBUG")) {
+        std::fprintf(stderr, "circle %d (%.3f %.3f r %.3f a %.0f): %d cand, %d arcs [%f %f] all %d:", i, list[i].x, list[i].y, list[i].r, list[i].attract, nc, n_arcs, arc_a, arc_b, (int)all_valid);
+        for (int k = 0; k < nc; k++) std::fprintf(stderr, " %.4f(%+.3g)", cand[k], clamp_validity(list, i, 0.5 * (cand[k] + ((k + 1 < nc) ? cand[k + 1] : cand[0] + two_pi))));
+        std::fprintf(stderr, "\n");
+    }
+    out->bw = 0.f;
+    double mid = 0, hw = 0;
+    if (n_arcs == 0) {
+        out->mx = 1.f; out->my = 0.f;
+        out->chw = all_valid ? -2.f : 2.f;
+        if (!all_valid && !everything && nc) {
+            // no valid arc meets the query range; an arc elsewhere must not leak in: "never" is right as long as
+            // the safety net below (restricted to the range) agrees
+        }
+    } else if (n_arcs == 1) {
+        mid = 0.5 * (arc_a + arc_b);
+        hw = 0.5 * (arc_b - arc_a);
+        out->mx = (float)std::cos(mid);
+        out->my = (float)std::sin(mid);
+        out->chw = (float)std::cos(hw);
+    } else {
+        TOL_REJECT("the valid directions are more than one arc");
+    }
+    // doubt band around the two arc ends: the largest offset at which the clamp point is still within eps
+    // of the validity boundary (geometric scan), doubled
+    double dmax = 0;
+    if (n_arcs == 1) {
+        const double ends[2] = {arc_a, arc_b};
+        double w_band = 0;
+        for (double e : ends)
+            for (int sgn = -1; sgn <= 1; sgn += 2) {
+                if (!in_query(e)) continue; // this end is never asked about
+                double last = 0;
+                for (double d = 1e-9; d < 0.05; d *= 1.25)
+                    if (std::fabs(clamp_validity(list, i, e + sgn * d)) < eps) last = d;
+                if (last > 0.02) TOL_REJECT("a validity boundary is nearly tangent at an arc end");
+                last = 2.0 * last + 1e-9;
+                dmax = std::max(dmax, last);
+                w_band = std::max(w_band, std::fabs(std::cos(e + sgn * last - mid) - std::cos(hw)));
+            }
+        if (hw < 2 * dmax || (3.141592653589793 - hw) < 2 * dmax) TOL_REJECT("a sliver of an arc (or of a gap)");
+        out->bw = (float)(w_band + 1e-6); // + the float evaluation of w itself (a few ulp of 1)
+    }
+    // safety net on a dense sample: the arc form agrees with the direct evaluation wherever that is certain
+    const int kSamples = 4096;
+    for (int s = 0; s < kSamples; s++) {
+        const double th = two_pi * (s + 0.5) / kSamples;
+        if (!in_query(th)) continue;
+        const double g = clamp_validity(list, i, th);
+        const double w = (double)out->mx * std::cos(th) + (double)out->my * std::sin(th) - (double)out->chw;
+        if (std::fabs(g) < eps) {
+            if (!(std::fabs(w) < (double)out->bw)) TOL_REJECT("an uncertain direction outside the doubt band");
+        } else if ((g < 0) != (w >= 0)) {
+            if (!(std::fabs(w) < (double)out->bw)) TOL_REJECT("the arc form disagrees with the direct evaluation");
+        }
+    }
+    return true;
+}
+
+} // namespace
+
+void lrm_compile_tol(const LrmCompiledLeg& L, LrmTolLeg* out) {
+    std::memset(out, 0, sizeof *out);
+    bool ok = L.fast_ok != 0;
+    // How far the reference's float clamp point (force_clamp_on_circle one_leg.cu:42-63: sub, sqrt, div, mul, add)
+    // and its float validation (distance_to_circumf :31-41) can be from the exact ones: a few ulp of the plane
+    // coordinates each; 16u * fast_scale (~3e-4 mm) -- below CIRCLE_MARGIN, so that the designed tangencies
+    // (a from-above circle touching the outer circle from inside, valid by the margin alone) stay certain.
+    const double eps = 16.0 * 5.9604645e-8 * (double)L.fast_scale;
+    const double pi = 3.141592653589793, slack = 2e-3;
+    // the sector of directions find_region (circles.cu.h:48-78) assigns to list k = upper * 2 + fully_extended
+    double q_lo[4], q_hi[4];
+    {
+        const double mid = L.region_mid, fs0 = L.full_sat[0], fs1 = L.full_sat[1];
+        q_lo[0] = -pi;                 q_hi[0] = std::min(mid, fs0); // lower, not fully extended
+        q_lo[1] = fs0;                 q_hi[1] = mid;                // lower, fully extended
+        q_lo[2] = std::max(mid, fs1);  q_hi[2] = pi;                 // upper, not fully extended
+        q_lo[3] = mid;                 q_hi[3] = fs1;                // upper, fully extended
+    }
+    double r_outer = 0;
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < LRM_N_CIRCLES; i++) {
+            auto& c = out->circ[k][i];
+            const LrmCircle& ci = L.lists[k][i];
+            c.x = ci.x; c.y = ci.y; c.gs = L.lean[k][i].gs; c.c = L.lean[k][i].c;
+            c.r = ci.r;
+            c.mx = 1.f; c.my = 0.f; c.chw = 2.f; c.bw = 0.f;
+            double qa = 0, qb = 7; // everything
+            if (ci.x == 0.f && ci.y == 0.f) { // centred on the femur joint: the clamp direction is the point's own
+                qa = q_lo[k] - slack;
+                qb = std::max(q_hi[k], q_lo[k]) + slack; // an empty sector (never selected) keeps a token range
+            }
+            if (ok || std::getenv("LRM_TOL_DEBUG")) ok = clamp_arc(L.lists[k], i, eps, qa, qb, &c) && ok;
+            out->feat[k * LRM_N_CIRCLES + i] = ci;
+            r_outer = std::max(r_outer, std::hypot((double)ci.x, (double)ci.y) + (double)ci.r);
+        }
+    // corner points: exact repeats are already gone; near-repeats (closer than 1e-4 mm: a tenth of the
+    // smallest tie band) would put every point whose nearest target they are in doubt -- keep the first,
+    // as the reference's strict "closer than" does for exact ties
+    out->n_corners = 0;
+    for (int i = 0; i < L.n_ucorners; i++) {
+        bool dup = false;
+        for (int j = 0; j < out->n_corners; j++)
+            dup = dup || std::hypot((double)out->feat[16 + j].x - (double)L.ucorner_x[i],
+                                    (double)out->feat[16 + j].y - (double)L.ucorner_y[i]) < 1e-4;
+        if (dup) continue;
+        out->feat[16 + out->n_corners] = LrmCircle{L.ucorner_x[i], L.ucorner_y[i], 0.f, 1.f};
+        r_outer = std::max(r_outer, std::hypot((double)L.ucorner_x[i], (double)L.ucorner_y[i]));
+        out->n_corners++;
+    }
+    for (int i = out->n_corners; i < LRM_N_CORNERS; i++) out->feat[16 + i] = LrmCircle{0.f, 0.f, 0.f, 1.f};
+    for (int i = 0; i < 12; i++) out->aff[i] = L.aff_global[i];
+    {   // coxa-frame vector -> output frame: place_over_coxa<Reverse> (one_leg.cu:17), z_unrotateInPlace
+        // (one_leg_global.cu:33-39), qtRotate(q, .) (one_leg_global.cu:99), composed in double
+        const double c = L.cos_pitch_rev, s = L.sin_pitch_rev, cb = L.cos_body, sb = L.sin_body;
+        const double Rp[3][3] = {{c, 0, -s}, {0, 1, 0}, {s, 0, c}};
+        const double Rz[3][3] = {{cb, sb, 0}, {-sb, cb, 0}, {0, 0, 1}};
+        double Rq[3][3], T[3][3];
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) Rq[r][k] = 2.0 * L.fwd_rot[3 * r + k] + (r == k ? 1.0 : 0.0);
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) {
+                T[r][k] = 0;
+                for (int j = 0; j < 3; j++) T[r][k] += Rz[r][j] * Rp[j][k];
+            }
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) {
+                double v = 0;
+                for (int j = 0; j < 3; j++) v += Rq[r][j] * T[j][k];
+                out->back[3 * r + k] = (float)v;
+            }
+    }
+    out->yaw_cs[0] = L.dir_cos[3]; out->yaw_cs[1] = L.dir_sin[3];
+    out->yaw_cs[2] = L.dir_cos[4]; out->yaw_cs[3] = L.dir_sin[4];
+    for (int i = 0; i < 3; i++) { out->dir_cos[i] = L.dir_cos[i]; out->dir_sin[i] = L.dir_sin[i]; }
+    out->region_lut = L.region_lut;
+    out->coxa_length = L.coxa_length;
+    out->band_base = L.band_base;
+    out->band_slope = L.band_slope;
+    out->r_outer = (float)(r_outer * 1.0001 + 0.01);
+    out->tol_ok = ok ? 1 : 0;
 }

@@ -15,3 +15,9 @@ void lrm_host_leg_factory(float azimut, float body2coxa, float coxa_pitch_deg, f
                           float tibia2femur, float femur2tip, float coxa_angle_deg,
                           float femur_angle_deg, float tibia_angle_deg, float tib_abs_pos,
                           float tib_abs_neg, LrmLegDimensions* out);
+
+// Tolerance mode (LRM_MODE_TOL, lrm_point_tol.h): the block its per-point code reads, derived from an
+// already compiled leg.  out->tol_ok == 0 when the leg's geometry does not fit the mode's assumptions
+// (the valid part of some circle is not one arc, a clamp-validity boundary grazes instead of crossing,
+// the leg is not eligible for the filters at all): callers then use LRM_MODE_FAST for that leg.
+void lrm_compile_tol(const LrmCompiledLeg& L, LrmTolLeg* out);

@@ -1,0 +1,321 @@
+// lrm_point_tol.h -- contract-tolerance evaluation (LRM_MODE_TOL) of reach + distance.
+//
+// BASELINE.json's contract for this path is "reach mask bit-exact, distance field within 1e-5 relative".
+// LRM_MODE_STRICT / LRM_MODE_FAST deliver tolerance 0 on the distance field and pay for it: two FP64
+// sincosf, one FDLIBM atan2f, IEEE divisions and square roots, the strict clamp of the winner and strict norms
+// for BOTH yaw candidates -- about 1000 VALU instructions per point.  This mode keeps
+// the DECISIONS of the reference (so the mask stays bit-exact and the vector lands on the same boundary
+// feature) and computes the VALUES with plain FP32 FMA arithmetic and v_rsq_f32:
+//
+//  * no trigonometry at all per point: a yaw candidate rotates the point either onto its own meridian
+//    plane ((cos, sin) = +-(x, y)/r from one v_rsq_f32) or onto a yaw-limit plane ((cos, sin) are leg constants);
+//    every comparison of an angle with a leg constant is the sign of a cross / dot product with that
+//    constant's direction (finish_finding_closest one_leg.cu:215-230 compares atan2f values);
+//  * the two candidates of distance_circles (one_leg.cu:321-341) are the SAME configuration when one of them is
+//    "mega-saturated" onto the other (|yaw| within pi/2 - limit of the x axis): one plane evaluation instead of
+//    two (the strict modes must run both: the reference's pick between them is rounding noise, but both picks
+//    are the same vector to 1e-7);
+//  * the yaw-limit alternative (one_leg.cu:258-274) is w * (-sin, cos) of the nearer limit plane, w being the
+//    cross product already taken for the sector test;
+//  * in the plane (multi_circle_clamp one_leg.cu:91-145): squared distances rank the candidates (no sqrt
+//    for the corner points), "the clamp point of circle i passes the other three circles" is ONE dot
+//    product against the arc of circle i that is valid (LrmTolLeg::Circle, built and verified on the host),
+//    and only the winner's clamp is formed: delta = (p - c) * (1 - r / |p - c|).
+//
+// Every decision is taken with a conservative band (mm) exactly as in lrm_point_fast.h; a point with ANY
+// decision inside its band is reported in `doubt` and its outputs are not used: the kernel queues it and a
+// second, small launch re-evaluates the queue with the bit-exact filtered code (lrm_kernels.hip,
+// tol_fixup_kernel).  So for every point the result is either the bit-exact one or within the tolerance
+// of it (tests/test_tol_cpu.py, tests/test_gpu_tol.py state and check the metric).
+//
+// Error model (u = 2^-24, S = |p|_1 + body + fast_scale): the coxa-frame point comes from one FMA affine map,
+// <= 22u S away from the strict chain (as the lean reach filter); the plane abscissa sgn * r from v_rsq_f32
+// (1 ulp) is <= 8u r from the strict x cos(a) - y sin(a); squared distances by FMA carry 2u relative.  The
+// decision band is the lean reach filter's (LRM_BAND * S-like, >= 4.5x the worst case); ties between two
+// distances taken from the SAME plane point move by at most twice the point's own error, so the tie band is a
+// quarter of the decision band (LRM_TOL_TIE; still >= 2x the worst case; tests/test_tol_cpu.py shrinks the bands
+// until mismatches appear to keep the margin honest).
+#pragma once
+#include "lrm_point_fast.h"
+
+#ifndef LRM_TOL_AMP2
+#define LRM_TOL_AMP2 64.0f // (largest accepted r / |p - c| of the winning clamp)^2
+#endif
+#ifndef LRM_TOL_RMIN
+#define LRM_TOL_RMIN 8.0f
+#endif
+#ifndef LRM_TOL_CAND_UNROLL
+#define LRM_TOL_CAND_UNROLL 2 // 2: the candidate evaluation is instantiated twice; 1: one copy executed twice
+#endif
+#ifndef LRM_TOL_CIRCLE_UNROLL
+#define LRM_TOL_CIRCLE_UNROLL 2
+#endif
+// all lanes of the wave agree (device) / this point (host)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LRM_TOL_ALL(c) (__all(c))
+#else
+#define LRM_TOL_ALL(c) (c)
+#endif
+#ifndef LRM_TOL_TIE
+#define LRM_TOL_TIE 0.25f
+#endif
+
+// doubt bits (host: statistics; any bit sends the point to the bit-exact re-evaluation).  On the device they
+// all collapse to one bit, so that the compiler ORs lane masks on the scalar unit instead of materialising and
+// OR-ing one VGPR constant per test.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LRM_TOL_STATS)
+#define LRM_TD_YAW 1u
+#define LRM_TD_REGION 1u
+#define LRM_TD_CLAMP 1u
+#define LRM_TD_TIE 1u
+#define LRM_TD_NONE 1u
+#define LRM_TD_LIMIT 1u
+#define LRM_TD_PICK 1u
+#else
+#define LRM_TD_YAW 1u      // yaw within the band of a sector boundary (limit, limit +- pi/2), or the point near the coxa axis
+#define LRM_TD_REGION 2u   // find_region or point-in-circle decision inside the band
+#define LRM_TD_CLAMP 4u    // clamp-point validity inside its band
+#define LRM_TD_TIE 8u      // the two nearest clamp targets tie
+#define LRM_TD_NONE 16u    // no clamp target at all (the reference then returns the raw point), or an ill-conditioned clamp
+#define LRM_TD_LIMIT 32u   // yaw-limit alternative ties with the in-plane distance, or the two limits tie
+#define LRM_TD_PICK 64u    // the two yaw candidates tie
+#endif
+#define LRM_TD_SECOND 0x10000u // statistic only: the second candidate could not be pruned by its lower bound
+
+struct LrmTolTables {
+    const LrmTolLeg::Circle* circ; // [16]
+    const LrmCircle* feat;         // [LRM_TOL_FEATS]
+};
+
+// kind of a yaw candidate from the sign pattern of (w_max, u_max, w_min, u_min) (bit set = negative):
+// code 0: the point's own meridian plane (+r), 1: the opposite one (-r), 2: the max-limit plane, 3: the min-limit
+// plane.  finish_finding_closest (one_leg.cu:215-230) with `angle` = yaw of the point (direct) or yaw -+ pi (flip):
+//   inside [min, max]                 -> unsaturated: own plane (direct) / opposite plane (flip)
+//   (max, max + pi/2] / [min - pi/2, min) -> clamped to that limit
+//   beyond                            -> "mega": sat = angle -+ pi: opposite plane (direct) / own plane (flip)
+LRM_HD constexpr uint32_t lrm_tol_kind(uint32_t pat) { // 0 inside, 2 / 3 clamped to max / min, 1 beyond
+    return ((pat & 5u) == 1u) ? 0u : (((pat & 3u) == 0u) ? 2u : (((pat & 12u) == 4u) ? 3u : 1u));
+}
+LRM_HD constexpr uint32_t lrm_tol_lut(bool flip) {
+    uint32_t lut = 0;
+    for (uint32_t pat = 0; pat < 16; pat++) {
+        uint32_t k = lrm_tol_kind(flip ? (pat ^ 15u) : pat);
+        if (flip && k < 2u) k ^= 1u; // the flipped candidate sees the mirrored point: own <-> opposite plane
+        lut |= k << (2 * pat);
+    }
+    return lut;
+}
+
+// eval_plane_circles<DIST> + multi_circle_clamp (one_leg.cu:91-145, :167-208) at plane point (u, z):
+// (du, dz) = point - nearest valid clamp target; `valid` = the point passes its region's four circles.
+LRM_HD void lrm_tol_plane(const LrmTolLeg& L, const LrmTolTables T, float u, float z, float band, float tau,
+                          float& du, float& dz, bool& valid, uint32_t& doubt) {
+    const float x = u - L.coxa_length;
+    // region (circles.cu.h:48-78), as lrm_plane_dist_fast
+    const float t_mid = __builtin_fmaf(L.dir_cos[0], z, -(L.dir_sin[0] * x));
+    const float t_s0 = __builtin_fmaf(L.dir_cos[1], z, -(L.dir_sin[1] * x));
+    const float t_s1 = __builtin_fmaf(L.dir_cos[2], z, -(L.dir_sin[2] * x));
+    const uint32_t reg = lrm_region_from_signs(L.region_lut, t_mid, t_s0, t_s1, z) * LRM_N_CIRCLES;
+    float macc = fminf(fminf(fabsf(t_mid), fabsf(t_s0)), fminf(fabsf(t_s1), fmaxf(x, fabsf(z))));
+    float vacc = -3.0e38f, cacc = 3.0e38f;
+    uint32_t lo = 0x7f80000fu, hi = 0x7f80000fu; // the two smallest keys: squared distance bits | candidate number
+    const LrmTolLeg::Circle* ct = T.circ + reg;
+#pragma unroll LRM_TOL_CIRCLE_UNROLL
+    for (int i = 0; i < LRM_N_CIRCLES; i++) {
+        const LrmTolLeg::Circle c = ct[i];
+        const float vx = x - c.x, vy = z - c.y;
+        const float m = __builtin_fmaf(vy, vy, vx * vx);
+        // validity of the point itself (mm, < 0 = valid).  Only the LARGEST value decides: below -band every
+        // circle is passed with margin, above +band one circle fails with margin whatever the others say.
+        vacc = fmaxf(vacc, __builtin_fmaf(m, c.gs, c.c));
+        const float rs = LRM_FAST_RSQ(m);
+        const float mag = m * rs;
+        const float d = c.r - mag;
+        // is the clamp point valid for the other three circles: one arc test, scaled by |p - c|.  (At the centre
+        // of the circle, where the reference switches to a fixed direction (one_leg.cu:54-58), |w| <= 3 |p - c|
+        // is inside the band; should that clamp win all the same, LRM_TOL_AMP2 below catches it.)
+        const float w = __builtin_fmaf(-c.chw, mag, __builtin_fmaf(vx, c.mx, vy * c.my));
+        cacc = fminf(cacc, __builtin_fmaf(-c.bw, mag, fabsf(w)));
+        // an invalid clamp ranks as +huge: max(d^2, -1e30 w)
+        const float kf = fmaxf(d * d, w * -1.0e30f);
+        const uint32_t k = (lrm_f2u(kf) & ~15u) | (uint32_t)i;
+        hi = lrm_umed3(lo, hi, k);
+        lo = lo < k ? lo : k;
+    }
+    valid = vacc < 0.f;
+    // corner points only matter when the point itself is invalid (one_leg.cu:109-116)
+    const uint32_t keep = valid ? 0u : 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < LRM_N_CORNERS; i++) {
+        if (i < L.n_corners) { // wave-uniform
+            const LrmCircle c = T.feat[4 * LRM_N_CIRCLES + i];
+            const float vx = x - c.x, vy = z - c.y;
+            const float m = __builtin_fmaf(vy, vy, vx * vx);
+            uint32_t k = (lrm_f2u(m) & ~15u) | (uint32_t)(LRM_N_CIRCLES + i);
+            k = (k & keep) | (0x7f80000fu & ~keep);
+            hi = lrm_umed3(lo, hi, k);
+            lo = lo < k ? lo : k;
+        }
+    }
+    const float lo2 = lrm_u2f(lo & ~15u), hi2 = lrm_u2f(hi & ~15u);
+    // |b - a| < tau  <=>  b^2 < a^2 + tau (2a + tau); the keys dropped 4 mantissa bits (< 2e-6 relative)
+    const float a = LRM_FAST_SQRT(lo2);
+    const float tie_thr = __builtin_fmaf(lo2, 4.0e-6f, __builtin_fmaf(tau, __builtin_fmaf(2.0f, a, tau), lo2));
+    // the winner's clamp: delta = (p - c)(1 - r / |p - c|); a corner point is a circle of radius 0
+    const uint32_t win = lo & 15u;
+    const LrmCircle f = T.feat[win < LRM_N_CIRCLES ? reg + win : 3 * LRM_N_CIRCLES + win];
+    const float vx = x - f.x, vy = z - f.y;
+    const float m = __builtin_fmaf(vy, vy, vx * vx);
+    const float s = __builtin_fmaf(-f.r, LRM_FAST_RSQ(m), 1.0f);
+    du = vx * s;
+    dz = vy * s;
+    uint32_t lu = 0;
+    lu |= (!(macc > band) || !(fabsf(vacc) > band)) ? LRM_TD_REGION : 0u;
+    lu |= !(cacc > tau) ? LRM_TD_CLAMP : 0u;
+    lu |= !(hi2 > tie_thr) ? LRM_TD_TIE : 0u;
+    // Near the centre of the winning circle the clamp point amplifies the rounding of the plane point by
+    // r / |p - c| (the reference's own result is just as sensitive: the two would differ by amplified noise):
+    // beyond 4x the point goes to the bit-exact code.  A corner point has r = 0: only m = 0 (0 * inf) is caught.
+    lu |= (!(lo2 < 1.0e30f) || !(m * LRM_TOL_AMP2 > f.r * f.r)) ? LRM_TD_NONE : 0u;
+    doubt |= lu;
+#if defined(LRM_TOL_TRACE)
+    printf("  plane u %.5f z %.5f x %.5f reg %u valid %d lo %08x hi %08x (lo2 %.6f hi2 %.6f) win %u feat(%.4f %.4f r %.4f) m %.5f d(%.5f %.5f) lu %x\n",
+           u, z, x, reg / 4, (int)valid, lo, hi, lo2, hi2, win, f.x, f.y, f.r, m, du, dz, lu);
+#endif
+}
+
+// distance_global + reachability_global (one_leg_global.cu:74-130) of one body-frame point.
+// p: in = the point, out = the distance vector.  Returns the reach / validity flag (the two coincide whenever
+// no decision is in doubt, see lrm_reach_from_dist).  doubt != 0: the outputs must not be used.
+LRM_HD bool lrm_dist_tol(const LrmTolLeg& L, const LrmTolTables T, LrmVec3& p, uint32_t& doubt) {
+    const float* a = L.aff;
+    const float x = __builtin_fmaf(a[0], p.x, __builtin_fmaf(a[1], p.y, __builtin_fmaf(a[2], p.z, a[3])));
+    const float y = __builtin_fmaf(a[4], p.x, __builtin_fmaf(a[5], p.y, __builtin_fmaf(a[6], p.z, a[7])));
+    const float z = __builtin_fmaf(a[8], p.x, __builtin_fmaf(a[9], p.y, __builtin_fmaf(a[10], p.z, a[11])));
+    // non-finite input: the band is nan/inf and every "> band" test fails closed (doubt)
+    const float band = __builtin_fmaf(fabsf(p.x) + fabsf(p.y) + fabsf(p.z), L.band_slope, L.band_base);
+    const float tau = band * LRM_TOL_TIE;
+    const float m2 = __builtin_fmaf(y, y, x * x);
+    const float rs = LRM_FAST_RSQ(m2);
+    const float r = m2 * rs;
+    const float cu = x * rs, su = y * rs; // cos / sin of the point's yaw
+    const float cM = L.yaw_cs[0], sM = L.yaw_cs[1], cm = L.yaw_cs[2], sm = L.yaw_cs[3];
+    // abscissa / offset of the point in the two yaw-limit planes; their signs are the sector tests
+    const float uM = __builtin_fmaf(x, cM, y * sM), wM = __builtin_fmaf(y, cM, -(x * sM));
+    const float um = __builtin_fmaf(x, cm, y * sm), wm = __builtin_fmaf(y, cm, -(x * sm));
+    const uint32_t pat = (lrm_f2u(wM) >> 31) | ((lrm_f2u(uM) >> 30) & 2u) | ((lrm_f2u(wm) >> 29) & 4u) |
+                         ((lrm_f2u(um) >> 28) & 8u);
+    constexpr uint32_t kLutD = lrm_tol_lut(false), kLutF = lrm_tol_lut(true);
+    const uint32_t codeD = (kLutD >> (pat << 1)) & 3u, codeF = (kLutF >> (pat << 1)) & 3u;
+    // inside [min, max]: the only kind of candidate that can be reachable and that sees the yaw-limit alternative
+    const bool inD = (pat & 5u) == 1u, inF = (pat & 5u) == 4u;
+    const bool same = codeD == codeF; // one of them is mega-saturated onto the other
+    const float ymin = fminf(fminf(fabsf(wM), fabsf(uM)), fminf(fabsf(wm), fabsf(um)));
+    uint32_t lu = !(ymin > band) ? LRM_TD_YAW : 0u;
+    // Close to the coxa axis the yaw direction (x, y) / r amplifies the rounding of (x, y) by |du| / r (for the
+    // reference just as much): inside LRM_TOL_RMIN the point goes to the bit-exact code.
+    lu |= !(r > LRM_TOL_RMIN) ? LRM_TD_YAW : 0u;
+
+    // one copy of the candidate evaluation, executed twice (k = 0 direct, 1 flipped)
+    float Xa = 0.f, Ya = 0.f, Za = 0.f, na = 0.f, Xb = 0.f, Yb = 0.f, Zb = 0.f, nb = 0.f;
+    bool fa = false, fb = false;
+#pragma unroll LRM_TOL_CAND_UNROLL
+    for (int k = 0; k < 2; k++) {
+        if (k && LRM_TOL_ALL(same)) break; // the second candidate is the first one again
+        const uint32_t code = k ? codeF : codeD;
+        const bool lim = code >= 2u, mn = code == 3u, neg = code == 1u;
+        // rotate the point by -sat: (cos, sin)(sat) = +-(x, y) / r for its own / the opposite meridian plane,
+        // the limit's constants for a limit plane
+        const float c = lim ? (mn ? cm : cM) : lrm_u2f(lrm_f2u(cu) ^ (neg ? 0x80000000u : 0u));
+        const float s = lim ? (mn ? sm : sM) : lrm_u2f(lrm_f2u(su) ^ (neg ? 0x80000000u : 0u));
+        const float u = __builtin_fmaf(x, c, y * s);
+        const float w = lim ? __builtin_fmaf(y, c, -(x * s)) : 0.f;
+        float du = 0.f, dz = 0.f;
+        bool valid = false;
+        uint32_t d = 0;
+        lrm_tol_plane(L, T, u, z, band, tau, du, dz, valid, d);
+        // A candidate clamped to a yaw limit whose plane point is valid: the yaw-limit alternative of
+        // one_leg.cu:258-274 runs with th = -(limit - sat) = 0, d_limit = |w| < |(du, w, dz)|: the result is
+        // the offset from the limit plane alone
+        // -- unless |(du, dz)| is so small that sqrt(du^2 + w^2 + dz^2) ROUNDS to |w|: the reference's
+        // `d_clamped > d_limit` is then false and it keeps the in-plane part (a vector 3e-4 |w| long at most,
+        // still 30x the tolerance).  q / w^2 below 2^-25 cannot move the float sum, above 2^-20 always does;
+        // in between the outcome depends on the rounding of the sum and of the square root: doubt.
+        if (lim && valid) {
+            const float q = __builtin_fmaf(du, du, dz * dz), w2 = w * w;
+            if (q > w2 * 9.6e-7f) du = dz = 0.f;
+            else if (!(q < w2 * 2.9e-8f)) d |= LRM_TD_LIMIT;
+        }
+        if (!(k && same)) lu |= d;
+        const float X = __builtin_fmaf(du, c, -(w * s)), Y = __builtin_fmaf(du, s, w * c);
+        const float nn = __builtin_fmaf(du, du, __builtin_fmaf(w, w, dz * dz));
+        const bool fl = valid && (k ? inF : (inD || (same && inF)));
+#if defined(LRM_TOL_TRACE)
+        printf(" cand %d code %u c %.6f s %.6f u %.5f w %.5f -> X %.5f Y %.5f Z %.5f n %.6f flag %d\n", k, code, c, s, u, w, X, Y, dz, sqrtf(nn), (int)fl);
+#endif
+        if (k) { Xb = X; Yb = Y; Zb = dz; nb = nn; fb = fl; }
+        else { Xa = X; Ya = Y; Za = dz; na = nn; fa = fl; }
+    }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    const float na0 = na, nb0 = nb;
+#endif
+    // the yaw-limit alternative (one_leg.cu:258-274) of the candidate inside the yaw range, when it is valid:
+    // the nearer limit plane wins over the in-plane boundary when it is closer
+    {
+        const bool onB = inF && !same;
+        const float nu = onB ? nb : na;
+        if (onB ? fb : fa) {
+            const float aM = fabsf(wM), am = fabsf(wm);
+            const float dl = fminf(aM, am), dl2 = dl * dl;
+            const float thr = tau * __builtin_fmaf(2.0f, dl, tau);
+            // in doubt: the two distances tie, or the alternative is (or may be) taken and the two limit planes tie
+            // (the reference picks by `angle > coxa_mid`; on the symmetry plane of a symmetric leg -- the bench
+            // grid, y = 0 -- both are the same distance, which only matters when the alternative wins)
+            if (!(fabsf(nu - dl2) > thr) || (!(nu < dl2 - thr) && !(fabsf(aM - am) > tau))) lu |= LRM_TD_LIMIT;
+            if (nu > dl2) {
+                const bool useM = aM < am;
+                const float wl = useM ? wM : wm, sl = useM ? sM : sm, cl = useM ? cM : cm;
+                const float X = -(wl * sl), Y = wl * cl;
+                if (onB) { Xb = X; Yb = Y; Zb = 0.f; nb = dl2; }
+                else { Xa = X; Ya = Y; Za = 0.f; na = dl2; }
+            }
+        }
+    }
+    // distance_circles' pick (one_leg.cu:334): equal validities -> the shorter vector, else the valid one
+    bool useD = true;
+    if (!same) {
+        const float nmin = LRM_FAST_SQRT(fminf(na, nb));
+        const float thr = tau * __builtin_fmaf(2.0f, nmin, tau);
+        const bool eq = fa == fb;
+        if (eq && !(fabsf(na - nb) > thr)) lu |= LRM_TD_PICK;
+        useD = eq ? (na < nb) : fa;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        // statistic (host only): could one candidate have been skipped?  The squared norm of a candidate is at
+        // least lb = w^2 + (|(u - coxa, z)| - r_outer)+^2.  Evaluate the candidate with the smaller bound first;
+        // the other one cannot win when the first is valid or already shorter than the other's bound.
+        {
+            float lb[2];
+            for (int k = 0; k < 2; k++) {
+                const uint32_t code = k ? codeF : codeD;
+                const bool lim = code >= 2u, mn = code == 3u, neg = code == 1u;
+                const float u = lim ? (mn ? um : uM) : (neg ? -r : r);
+                const float w = lim ? (mn ? wm : wM) : 0.f;
+                const float ux = u - L.coxa_length;
+                const float out = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(ux, ux, z * z)) - L.r_outer, 0.f);
+                lb[k] = __builtin_fmaf(w, w, out * out);
+            }
+            const bool firstD = inD || (!inF && lb[0] <= lb[1]); // a candidate inside the yaw range goes first
+            const float n1 = firstD ? na0 : nb0, lb2 = firstD ? lb[1] : lb[0];
+            const bool f1 = firstD ? fa : fb;
+            if (!f1 && !(n1 < lb2 - thr)) lu |= LRM_TD_SECOND;
+        }
+#endif
+    }
+    const float vx = useD ? Xa : Xb, vy = useD ? Ya : Yb, vz = useD ? Za : Zb;
+    const float* b = L.back;
+    p.x = __builtin_fmaf(b[0], vx, __builtin_fmaf(b[1], vy, b[2] * vz));
+    p.y = __builtin_fmaf(b[3], vx, __builtin_fmaf(b[4], vy, b[5] * vz));
+    p.z = __builtin_fmaf(b[6], vx, __builtin_fmaf(b[7], vy, b[8] * vz));
+    doubt |= lu;
+    return fa || fb;
+}

@@ -128,3 +128,35 @@ struct LrmCompiledLeg {
     float band_q;                        // LRM_BAND_DIST * 2 * fast_scale: clamp points live on the circles
     float pad3_[3];
 };
+
+// ---- tolerance mode (LRM_MODE_TOL, lrm_point_tol.h) -------------------------------------------
+// Everything the contract-tolerance evaluation reads, compiled from an LrmCompiledLeg (lrm_compile_tol).
+// A separate, smaller block: it travels by value in the kernarg segment next to nothing else.
+#define LRM_TOL_FEATS (4 * LRM_N_CIRCLES + LRM_N_CORNERS)
+struct LrmTolLeg {
+    // One record per circle of a region list (48 B, three ds_read_b128):
+    //   {x, y, gs, c}  point validity as in LrmCompiledLeg::LeanCircle: v = |p - centre|^2 * gs + c, valid <=> v < 0
+    //   {r, mx, my, chw}  the clamp point of this circle (radial projection of p) is valid for the other
+    //       three circles <=> its direction lies on ONE arc of the circle: u . (mx, my) >= chw
+    //       (chw = 2: never, chw = -2: always); evaluated as w = (p - centre) . (mx, my) - chw * |p - centre|
+    //   {bw}  doubt band of that test: |w| < bw * |p - centre| + tie band
+    struct alignas(16) Circle {
+        float x, y, gs, c;
+        float r, mx, my, chw;
+        float bw, pad[3];
+    } circ[4][LRM_N_CIRCLES];
+    // clamp targets by candidate number: the circles of list k at [k*4 + i], the corner points (radius 0) from
+    // [16] on: {x, y, r, -}
+    LrmCircle feat[LRM_TOL_FEATS];
+    float aff[12];        // body-frame point -> coxa frame (= LrmCompiledLeg::aff_global)
+    float back[9];        // coxa-frame vector -> output frame: Rq * Rz(+body_angle) * Rp(+coxa_pitch), row-major
+    float yaw_cs[4];      // cos/sin of max_coxa, cos/sin of min_coxa
+    float dir_cos[3], dir_sin[3]; // region rays (region_mid, full_sat[0], full_sat[1])
+    uint32_t region_lut;
+    float coxa_length;
+    float band_base, band_slope; // decision band (mm) = band_base + band_slope * |p|_1, as the lean reach filter
+    float r_outer;        // every clamp target lies within r_outer of the femur joint (femur + tibia)
+    int32_t n_corners;    // corner points in feat[16..], near-duplicates removed
+    int32_t tol_ok;       // 0: this leg must use LRM_MODE_FAST
+    float pad_[2];
+};

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Kernel times of the fused reach+distance launch in the three arithmetic modes on one GPU (HIP events, steady
+clocks), and the doubt statistics of the tolerance mode.  Usage: python tools/bench_modes.py [--points N]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=10_000_000)
+    ap.add_argument("--reps", type=int, default=300)
+    ap.add_argument("--modes", default="tol,fast,strict")
+    args = ap.parse_args()
+    import torch
+    import lrm_amd
+    rng = np.random.default_rng(42)
+    lo, hi = np.array([-200, -500, -500], np.float32), np.array([700, 500, 300], np.float32)
+    n = args.points
+    host = np.empty((3, n), np.float32)
+    for s in range(0, n, 2_000_000):
+        e = min(n, s + 2_000_000)
+        host[:, s:e] = (rng.random((e - s, 3), dtype=np.float32) * (hi - lo) + lo).T
+    cloud = torch.from_numpy(host).cuda()
+    x, y, z = cloud[0], cloud[1], cloud[2]
+    leg = lrm_amd.get_M2_leg(0.0)
+    mask = torch.empty(n, dtype=torch.uint8, device="cuda")
+    field = torch.empty((3, n), dtype=torch.float32, device="cuda")
+    bits = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
+    out = {"points": n}
+    modes = {"tol": lrm_amd.MODE_TOL, "fast": lrm_amd.MODE_FAST, "strict": lrm_amd.MODE_STRICT}
+    for name in args.modes.split(","):
+        lrm_amd.set_mode(modes[name])
+        fn = lambda: lrm_amd.device.reach_dist(x, y, z, leg, None, mask=mask, out=field, bits=bits)
+        for _ in range(150):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(args.reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / args.reps
+        out[name] = {"ms_per_call": ms, "evals_per_s": n / (ms * 1e-3), "hbm_GBs_algorithmic": 25 * n / (ms * 1e-3) / 1e9,
+                     "frac_of_8TBs": 25 * n / (ms * 1e-3) / 8e12}
+    lrm_amd.set_mode(lrm_amd.MODE_FAST)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

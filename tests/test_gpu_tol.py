@@ -1,0 +1,173 @@
+"""LRM_MODE_TOL on the GPU (run with -m gpu): the tolerance kernel + its fix-up launch, through the C ABI.
+
+Contract (include/lrm.h): reach mask, validity byte and ballot bit words BIT-IDENTICAL to the oracle; distance
+vector within the tolerance of tests/tolcheck.py (1e-5 relative to max(|d_ref|, |p| / 16)); points the kernel
+sent to its fix-up launch are bit-identical altogether."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, golden_cases, load_case, random_cloud
+from tolcheck import TOL, field_error, summary
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def tol_mode(lrm):
+    lrm.set_mode(lrm.MODE_TOL)
+    yield
+    lrm.set_mode(lrm.MODE_FAST)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "the gpu tests need a GPU"
+    return torch
+
+
+def soa(torch, pts):
+    """three separately allocated (16-byte aligned) component arrays"""
+    return tuple(torch.from_numpy(np.ascontiguousarray(pts[:, k])).cuda() for k in range(3))
+
+
+def packed(mask):
+    n = len(mask)
+    return np.packbits(np.pad(mask, (0, (-n) % 64)), bitorder="little").view(np.uint64)
+
+
+def check_outputs(pts, m, v, d, bits, want_m, want_v, want_d):
+    assert np.array_equal(m, want_m), "reach mask must be bit-exact in the tolerance mode"
+    if v is not None:
+        assert np.array_equal(v, want_v), "validity byte must be bit-exact in the tolerance mode"
+    if bits is not None:
+        assert np.array_equal(bits.view(np.uint64), packed(want_m))
+    e = field_error(pts, d, want_d)
+    assert e["metric"].max(initial=0.0) <= TOL, f"distance error {e['metric'].max():.3e}, abs {e['abs'].max():.3e} mm"
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_tol_device_api_matches_reference_fixture(lrm, torch_cuda, name):
+    c = load_case(name)
+    x, y, z = soa(torch_cuda, c["points"])
+    n = len(c["points"])
+    bits = torch_cuda.empty((n + 63) // 64, dtype=torch_cuda.int64, device="cuda")
+    m, d, bits = lrm.device.reach_dist(x, y, z, c["leg"], c["quat"], mask=torch_cuda.empty(n, dtype=torch_cuda.uint8, device="cuda"), bits=bits)
+    d1, v = lrm.device.dist(x, y, z, c["leg"], c["quat"])
+    torch_cuda.cuda.synchronize()
+    check_outputs(c["points"], m.cpu().numpy(), v.cpu().numpy(), d.cpu().numpy().T, bits.cpu().numpy(), c["mask"], c["valid"], c["dist"])
+    check_outputs(c["points"], m.cpu().numpy(), None, d1.cpu().numpy().T, None, c["mask"], c["valid"], c["dist"])
+
+
+@pytest.mark.parametrize("name", golden_cases("cube"))
+def test_tol_host_soa_api(lrm, name):
+    """lrm_dist_soa (on-disk layout host buffers) runs the tolerance kernels too."""
+    import ctypes as C
+    from lrm_amd import _capi
+    c = load_case(name)
+    pts = c["points"]
+    n = len(pts)
+    xs = [np.ascontiguousarray(pts[:, k]) for k in range(3)]
+    out = [np.zeros(n, np.float32) for _ in range(3)]
+    valid = np.zeros(n, np.uint8)
+    ms = C.c_float(0)
+    leg = np.ascontiguousarray(c["leg"], np.float32)
+    q = np.ascontiguousarray(c["quat"], np.float32)
+    _capi.check(lrm.lib().lrm_dist_soa(_capi._ptr(xs[0]), _capi._ptr(xs[1]), _capi._ptr(xs[2]), n, _capi._ptr(leg),
+                                       _capi._ptr(q), _capi._ptr(out[0]), _capi._ptr(out[1]), _capi._ptr(out[2]),
+                                       _capi._ptr(valid), C.addressof(ms)))
+    check_outputs(pts, valid, valid, np.stack(out, 1), None, c["valid"], c["valid"], c["dist"])
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 257, 4099, 100003, 1048577])
+def test_tol_ragged_sizes_and_guards(lrm, oracle, torch_cuda, n):
+    pts = random_cloud(n, seed=n + 11)
+    leg = lrm.get_M2_leg(0.3)
+    q = (0.98, 0.0, 0.15, 0.05)
+    x, y, z = soa(torch_cuda, pts)
+    mask = torch_cuda.full((n + 64,), 7, dtype=torch_cuda.uint8, device="cuda")
+    comps = [torch_cuda.full((n + 16,), -777.0, dtype=torch_cuda.float32, device="cuda") for _ in range(3)]
+    nw = (n + 63) // 64
+    bits = torch_cuda.full((nw + 2,), -1, dtype=torch_cuda.int64, device="cuda")
+    from lrm_amd import _capi
+    legp, qp = np.ascontiguousarray(leg, np.float32), np.ascontiguousarray(q, np.float32)
+    _capi.check(lrm.lib().lrm_reach_dist_bits_dev(x.data_ptr(), y.data_ptr(), z.data_ptr(), n, _capi._ptr(legp), _capi._ptr(qp),
+                                                  mask.data_ptr(), bits.data_ptr(), comps[0].data_ptr(), comps[1].data_ptr(),
+                                                  comps[2].data_ptr(), torch_cuda.cuda.current_stream().cuda_stream))
+    torch_cuda.cuda.synchronize()
+    want_d, want_v = oracle.dist(pts, leg, q)
+    d = np.stack([c[:n].cpu().numpy() for c in comps], 1)
+    check_outputs(pts, mask[:n].cpu().numpy(), None, d, bits[:nw].cpu().numpy(), oracle.reach(pts, leg, q), want_v, want_d)
+    assert (mask[n:] == 7).all() and (bits[nw:] == -1).all()
+    assert all((c[n:] == -777.0).all() for c in comps), "kernels must not write past n"
+
+
+def test_tol_random_cloud_1e6_legs_and_orientations(lrm, oracle, torch_cuda):
+    pts = random_cloud(1_000_000, seed=42)
+    x, y, z = soa(torch_cuda, pts)
+    worst = 0.0
+    for leg in (lrm.get_M2_leg(0.0), lrm.get_moonbot_leg(np.pi / 3), lrm.get_M2_leg(-2.0)):
+        for q in ((1, 0, 0, 0), (0.924, 0, -0.384, 0), (0.9, 0.1, 0.2, -0.3)):
+            m, d = lrm.device.reach_dist(x, y, z, leg, q)
+            torch_cuda.cuda.synchronize()
+            want_d, want_v = oracle.dist(pts, leg, q)
+            check_outputs(pts, m.cpu().numpy(), None, d.cpu().numpy().T, None, oracle.reach(pts, leg, q), want_v, want_d)
+            worst = max(worst, summary(pts, d.cpu().numpy().T, want_d)["max_metric"])
+    print(f"tolerance mode, 9e6 evaluations: max error metric {worst:.3e} (bound {TOL:.0e})")
+
+
+def test_tol_full_size_config2_1e7_points(lrm, oracle, torch_cuda):
+    """BASELINE config 2 at full size: mask equality and the error metric over all 1e7 points."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = 10_000_000
+    pts = random_cloud(n, seed=42)
+    leg = lrm.get_M2_leg(0.0)
+    x, y, z = soa(torch_cuda, pts)
+    bits = torch_cuda.empty((n + 63) // 64, dtype=torch_cuda.int64, device="cuda")
+    m, d, bits = lrm.device.reach_dist(x, y, z, leg, None, mask=torch_cuda.empty(n, dtype=torch_cuda.uint8, device="cuda"), bits=bits)
+    torch_cuda.cuda.synchronize()
+    m, d, bits = m.cpu().numpy(), d.cpu().numpy().T, bits.cpu().numpy()
+    parts = np.array_split(np.arange(n), 16)
+    with ThreadPoolExecutor(16) as ex:
+        res = list(ex.map(lambda idx: (oracle.reach(pts[idx[0]:idx[-1] + 1], leg), oracle.dist(pts[idx[0]:idx[-1] + 1], leg)), parts))
+    want_m = np.concatenate([r[0] for r in res])
+    want_d = np.concatenate([r[1][0] for r in res])
+    assert np.array_equal(m, want_m)
+    assert np.array_equal(bits.view(np.uint64), packed(want_m))
+    s = summary(pts, d, want_d)
+    exact = bits_equal(d, want_d).all(axis=1).mean()
+    print(f"config 2, tolerance mode: {s}; {exact:.4f} of the vectors bit-identical")
+    assert s["max_metric"] <= TOL
+
+
+def test_tol_queue_overflow_redoes_everything(lrm, oracle, torch_cuda):
+    """A cloud in which EVERY point is in doubt (all on the coxa axis neighbourhood): the doubt queue (n/8 slots)
+    overflows and the fix-up launch re-evaluates the whole cloud with the bit-exact code."""
+    rng = np.random.default_rng(5)
+    n = 200_000
+    leg = lrm.get_moonbot_leg(0.0)  # coxa axis: x = 181, y = 0 (no coxa pitch)
+    pts = np.stack([181.0 + rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(-300, 100, n)], 1).astype(np.float32)
+    x, y, z = soa(torch_cuda, pts)
+    m, d = lrm.device.reach_dist(x, y, z, leg, None)
+    torch_cuda.cuda.synchronize()
+    want_d, _ = oracle.dist(pts, leg)
+    assert np.array_equal(m.cpu().numpy(), oracle.reach(pts, leg))
+    assert bits_equal(d.cpu().numpy().T, want_d).all(), "an overflowing queue must give the bit-exact field"
+    # and the queue is usable again afterwards
+    pts2 = random_cloud(100_000, seed=3)
+    x, y, z = soa(torch_cuda, pts2)
+    m, d = lrm.device.reach_dist(x, y, z, leg, None)
+    torch_cuda.cuda.synchronize()
+    want_d, want_v = oracle.dist(pts2, leg)
+    check_outputs(pts2, m.cpu().numpy(), None, d.cpu().numpy().T, None, oracle.reach(pts2, leg), want_v, want_d)
+
+
+def test_tol_ineligible_leg_falls_back_to_bit_exact(lrm, oracle, torch_cuda):
+    odd = lrm.leg_factory(0.0, 181, -45, 65.5, 129, 135, 90.0, 90.0, 120.0, -5, -5)
+    pts = random_cloud(50_000, seed=9)
+    x, y, z = soa(torch_cuda, pts)
+    m, d = lrm.device.reach_dist(x, y, z, odd, None)
+    torch_cuda.cuda.synchronize()
+    want_d, _ = oracle.dist(pts, odd)
+    assert np.array_equal(m.cpu().numpy(), oracle.reach(pts, odd))
+    assert bits_equal(d.cpu().numpy().T, want_d).all()

@@ -1,0 +1,67 @@
+"""LRM_MODE_TOL on the host (lrm_dbg_tol_host = csrc/lrm_point_tol.h compiled for the CPU, WITHOUT the bit-exact
+re-evaluation of the doubtful points) against the oracle: every point the evaluation does not flag must have the
+oracle's mask bit for bit and a distance vector inside the tolerance (tests/tolcheck.py); the flagged fraction
+must stay small (those points cost a second pass on the GPU)."""
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_case, random_cloud
+from tolcheck import TOL, field_error
+
+QUATS = [(1, 0, 0, 0), (0.9848, 0, 0.1736, 0), (0.9397, 0, 0, 0.342), (0.9, 0.1, 0.2, -0.3)]
+
+
+def check(lrm, pts, leg, quat, want_mask, want_valid, want_dist, max_doubt):
+    m, d, doubt = lrm.dbg_tol_host(pts, leg, quat)
+    sure = (doubt & 0xffff) == 0
+    assert np.array_equal(m[sure], want_mask[sure]), "reach mask differs on points the filter calls certain"
+    assert np.array_equal(m[sure], want_valid[sure]), "validity byte differs on points the filter calls certain"
+    e = field_error(pts[sure], d[sure], want_dist[sure])
+    assert e["metric"].max(initial=0.0) <= TOL, f"distance error {e['metric'].max():.3e} (abs {e['abs'].max():.3e} mm)"
+    assert 1.0 - sure.mean() <= max_doubt, f"{1.0 - sure.mean():.4f} of the points are in doubt"
+    return 1.0 - sure.mean()
+
+
+@pytest.mark.parametrize("name", golden_cases("cube") + golden_cases("grid"))
+def test_tol_matches_reference_fixture(lrm, name):
+    c = load_case(name)
+    if not lrm.dbg_tol_ok(c["leg"], c["quat"]):
+        pytest.skip("leg not eligible for the tolerance mode (the library then uses LRM_MODE_FAST)")
+    # the planar bench grids (y = 0) contain the coxa axis (2-3 % of their points are within LRM_TOL_RMIN of it) and
+    # lie on the symmetry plane of the symmetric legs, where the two yaw-limit planes tie exactly (3 % for the
+    # moonbot leg): more doubt than a cloud
+    check(lrm, c["points"], c["leg"], c["quat"], c["mask"], c["valid"], c["dist"], 0.06)
+
+
+@pytest.mark.parametrize("name", golden_cases("boundary") + golden_cases("special"))
+def test_tol_on_boundary_hugging_points(lrm, name):
+    """Points constructed ON the decision boundaries: most are in doubt by design; the others must be right."""
+    c = load_case(name)
+    if not lrm.dbg_tol_ok(c["leg"], c["quat"]):
+        pytest.skip("leg not eligible")
+    check(lrm, c["points"], c["leg"], c["quat"], c["mask"], c["valid"], c["dist"], 1.0)
+
+
+@pytest.mark.parametrize("legname", ["m2", "moonbot"])
+@pytest.mark.parametrize("az", [0.0, np.pi / 3, -2.0])
+def test_tol_random_cloud_vs_oracle(lrm, oracle, legname, az):
+    leg = lrm.get_M2_leg(az) if legname == "m2" else lrm.get_moonbot_leg(az)
+    pts = random_cloud(200_000, seed=7)
+    for q in QUATS:
+        assert lrm.dbg_tol_ok(leg, q), "the two robots of the reference must be eligible in every orientation tested"
+        want_d, want_v = oracle.dist(pts, leg, q)
+        check(lrm, pts, leg, q, oracle.reach(pts, leg, q), want_v, want_d, 0.012)
+
+
+def test_tol_eligibility_of_odd_legs(lrm):
+    """Legs the filters cannot take (yaw limits at +-90 deg) are refused, never mis-evaluated."""
+    odd = lrm.leg_factory(0.0, 181, -45, 65.5, 129, 135, 90.0, 90.0, 120.0, -5, -5)
+    assert not lrm.dbg_tol_ok(odd)
+    with pytest.raises(lrm.LrmError):
+        lrm.dbg_tol_host(random_cloud(10), odd)
+
+
+def test_tol_nonfinite_inputs_are_in_doubt(lrm):
+    pts = np.array([[np.nan, 0, 0], [np.inf, 1, 2], [1e30, 1e30, -1e30], [0, 0, 0], [181.0, 0.0, 0.0]], np.float32)
+    _, _, doubt = lrm.dbg_tol_host(pts, lrm.get_M2_leg(0.0))
+    assert (doubt[:3] != 0).all()
