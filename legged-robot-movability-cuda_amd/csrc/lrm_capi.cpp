@@ -56,35 +56,18 @@ const LrmTolLeg& tol_leg(const LrmLegDimensions& leg, const float* quat, const L
     lrm_compile_tol(L, &t);
     return g_tol_cache.emplace(k, t).first->second;
 }
-// Device workspace of the doubt queue, one per (device, stream) in use: queue[cap] + {length, blocks done}.
-struct TolWorkspace {
-    uint32_t* queue = nullptr;
-    uint32_t* counters = nullptr;
-    size_t cap = 0;
-};
-std::map<std::pair<int, void*>, TolWorkspace> g_tol_ws;
-int tol_workspace(size_t n, void* stream, TolWorkspace** out) {
+// Device workspace of the doubt queue (fixed size, rewritten by every call), one per (device, stream) in use.
+std::map<std::pair<int, void*>, uint32_t*> g_tol_ws;
+int tol_workspace(void* stream, uint32_t** out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
-    TolWorkspace& w = g_tol_ws[std::make_pair(dev, stream)];
-    const size_t need = std::max<size_t>(n / 8, 4096); // more than 1/8 of the cloud in doubt: the fix-up redoes everything
-    if (!w.counters) {
+    uint32_t*& w = g_tol_ws[std::make_pair(dev, stream)];
+    if (!w) {
         void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, 2 * sizeof(uint32_t)), "hipMalloc tol counters");
-        w.counters = static_cast<uint32_t*>(p);
-        HIP_TRY(hipMemset(w.counters, 0, 2 * sizeof(uint32_t)), "hipMemset tol counters");
+        HIP_TRY(hipMalloc(&p, lrm_tol_queue_words() * sizeof(uint32_t)), "hipMalloc tolerance-mode queue");
+        w = static_cast<uint32_t*>(p);
     }
-    if (need > w.cap) {
-        if (w.queue) (void)hipFree(w.queue); // synchronises with whatever still reads it
-        w.queue = nullptr;
-        w.cap = 0;
-        void* p = nullptr;
-        const size_t cap = need + need / 2;
-        HIP_TRY(hipMalloc(&p, cap * sizeof(uint32_t)), "hipMalloc tol queue");
-        w.queue = static_cast<uint32_t*>(p);
-        w.cap = cap;
-    }
-    *out = &w;
+    *out = w;
     return LRM_OK;
 }
 
@@ -95,11 +78,10 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
     if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xffffffffull) {
         const LrmTolLeg& TL = tol_leg(leg, quat, L);
         if (TL.tol_ok) {
-            TolWorkspace* w = nullptr;
-            const int rc = tol_workspace(n, stream, &w);
+            uint32_t* w = nullptr;
+            const int rc = tol_workspace(stream, &w);
             if (rc != LRM_OK) return rc;
-            HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w->queue,
-                                        (uint32_t)std::min<size_t>(w->cap, 0xffffffffull), w->counters, (hipStream_t)stream),
+            HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, (hipStream_t)stream),
                     "tolerance-mode launch");
             return LRM_OK;
         }

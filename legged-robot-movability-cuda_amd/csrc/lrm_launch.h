@@ -10,11 +10,13 @@ hipError_t lrm_launch_reach_soa(const float* x, const float* y, const float* z, 
 hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const float* z, size_t n,
                                const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                                float* dz, bool fast, hipStream_t st);
-// LRM_MODE_TOL (lrm_tol_kernels.hip): the tolerance kernel + the fix-up of its doubt queue, two launches on `st`.
-// queue: qcap uint32 slots; counters: {queue length, fix-up blocks done}, both 0 between calls.  n < 2^32.
+// LRM_MODE_TOL (lrm_tol_kernels.hip): the tolerance kernel + the fix-up of its doubtful points, two launches on
+// `st`.  workspace: lrm_tol_queue_words() uint32 of device memory owned by the caller for the duration of both
+// launches (contents are rewritten by every call; no initialisation needed).
+size_t lrm_tol_queue_words(void);
 hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz,
-                               uint32_t* queue, uint32_t qcap, uint32_t* counters, hipStream_t st);
+                               uint32_t* workspace, hipStream_t st);
 hipError_t lrm_launch_reach_aos(const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask, bool fast,
                                 hipStream_t st);
 hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask,

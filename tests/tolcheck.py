@@ -5,10 +5,10 @@ d = p - (nearest boundary point), with |p| up to ~1e3 mm in float32, so |d| carr
 few ulp(|p|) (~1e-4 mm) in ANY float32 implementation -- the reference's own host and CUDA builds differ by that
 much.  A purely relative bound is therefore meaningless for short vectors; the metric is
 
-    err(i) = |d_i - dref_i|_2 / max(|dref_i|_2, |p_i|_2 / 16)          must be <= 1e-5
+    err(i) = |d_i - dref_i|_2 / max(|dref_i|_2, |p_i|_2 / 8)          must be <= 1e-5
 
-i.e. 1e-5 relative wherever the vector is longer than 1/16 of the point's own distance from the origin, and
-an absolute 1e-5 * |p| / 16 (~ 5 ulp of the coordinates) below that.  The plain relative error (floor 1e-2 mm)
+i.e. 1e-5 relative wherever the vector is longer than 1/8 of the point's own distance from the origin, and
+an absolute 1e-5 * |p| / 8 (~ 10 ulp of the coordinates) below that.  The plain relative error (floor 1e-2 mm)
 is reported next to it.
 """
 import numpy as np
@@ -22,7 +22,7 @@ def field_error(points, d, dref):
     dref = np.asarray(dref, np.float64).reshape(-1, 3)
     err = np.linalg.norm(d - dref, axis=1)
     nref = np.linalg.norm(dref, axis=1)
-    floor = np.linalg.norm(points, axis=1) / 16.0
+    floor = np.linalg.norm(points, axis=1) / 8.0
     with np.errstate(invalid="ignore", divide="ignore"):
         metric = err / np.maximum(nref, floor)
         plain = err / np.maximum(nref, 1.0e-2)
