@@ -124,6 +124,14 @@ int lrm_reach_cpu(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, c
 int lrm_dist_cpu(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                  float* dxyz_aos_out, uint8_t* valid_out /* may be NULL */, double* ms);
 
+/* ---- "RBDL-equivalent" CPU baseline: apply_RBDL, rbdl_benchmark.cpp:18-111 / RBDL_benchmark.h:5 ------
+ * The reference times RBDL's Levenberg-Marquardt position IK on the same targets (bench.cpp:158, 3 repeats,
+ * setting_bench.h:7).  RBDL is an external, unpinned dependency that is absent here: this is the same iteration
+ * (same chain incl. the /400 scaling, max_steps = 10, <= 5 starts) with closed-form kinematics.  PARITY UNPINNED:
+ * a timing baseline only; mask_out[i] = the solver converged (no joint limits, no coxa pitch, as the
+ * reference's RBDL model).  *ms = chrono milliseconds of the loop. */
+int lrm_rbdl_equiv_cpu(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, uint8_t* mask_out, double* ms);
+
 /* ---- device-resident entry points (no allocation, no copy, no sync) --------------------
  * Pointers are device pointers; coordinates are SoA (one f32 array per component: the same
  * layout the reference keeps on disk, several_leg.cpp:126-131).  `stream` is a hipStream_t

@@ -14,6 +14,8 @@
 //   reachability_global_kernel / distance_global_kernel  one_leg.cu.h:34-37 (tags here)
 //   get_M2_leg / get_moonbot_leg static_variables.h
 //   robot_full_struct            several_leg.cu.h:12-14
+//   apply_oct                    several_leg_octree.cu.h:4
+//   apply_RBDL                   RBDL_benchmark.h:5 (RBDL-equivalent solver, see below)
 // Error behaviour is the reference's: print to stderr and exit(EXIT_FAILURE)
 // (CUDA_CHECK_ERROR, cross_compiled.cu:12-20).
 #pragma once
@@ -99,6 +101,17 @@ inline double apply_dist_cpu(const Array<float3> input, const LegDimensions dim,
                                           &output.elements->x, nullptr, &ms),
                              "apply_dist_cpu");
     return ms;
+}
+
+// apply_RBDL, RBDL_benchmark.h:5 / rbdl_benchmark.cpp:18-111 (returns the loop's ms).  RBDL itself is an external,
+// unpinned dependency that is absent here: this runs the same Levenberg-Marquardt position-IK iteration on the
+// same chain ("RBDL-equivalent", lrm_rbdl_equiv_cpu): a timing baseline, its mask's parity is unpinned.
+inline float apply_RBDL(Array<float3> input, LegDimensions leg, Array<bool> output) {
+    double ms = 0;
+    lrm_compat_detail::check(lrm_rbdl_equiv_cpu(&input.elements->x, input.length, &leg,
+                                                reinterpret_cast<uint8_t*>(output.elements), &ms),
+                             "apply_RBDL");
+    return (float)ms;
 }
 
 // apply_oct, several_leg_octree.cu.h:4 / several_leg_octree.cu:391-488: replaces output.elements by a

@@ -66,6 +66,7 @@ def load():
         "lrm_dist_soa": [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp],
         "lrm_reach_cpu": [vp, sz, vp, vp, vp, vp],
         "lrm_dist_cpu": [vp, sz, vp, vp, vp, vp, vp],
+        "lrm_rbdl_equiv_cpu": [vp, sz, vp, vp, vp],
         "lrm_reach_dev": [vp, vp, vp, sz, vp, vp, vp, vp],
         "lrm_reach_bits_dev": [vp, vp, vp, sz, vp, vp, vp, vp, vp],
         "lrm_dist_dev": [vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp],
@@ -219,6 +220,15 @@ def apply_dist_cpu(xyz, leg, quat=None):
     check(load().lrm_dist_cpu(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(d), _ptr(v),
                               C.addressof(ms)))
     return d, v, ms.value
+
+
+def apply_rbdl_equiv(xyz, leg):
+    """apply_RBDL's work restated (RBDL-equivalent LM position IK, parity unpinned) -> (converged uint8[n], ms); CPU."""
+    xyz = _f32(xyz, (-1, 3))
+    mask = np.zeros(len(xyz), np.uint8)
+    ms = C.c_double(0)
+    check(load().lrm_rbdl_equiv_cpu(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(mask), C.addressof(ms)))
+    return mask, ms.value
 
 
 def morton_order(points):

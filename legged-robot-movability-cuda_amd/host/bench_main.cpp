@@ -4,10 +4,11 @@
 // distance}, planar grids x in [XMin,XMax], y = 0, z in [XMin (sic, bench.cpp:114), ZMax] at
 // pitch MinPix * 2^k <= MaxPix, `subsample` repeats each, one CSV row "N;ns_per_point" per
 // repeat (bench.cpp:164-171).  Written against include/lrm_compat.hpp, i.e. against the
-// reference's own API names.  The RBDL leg (compute index 4) is out of scope (external,
-// unpinned dependency).
+// reference's own API names.  Compute index 4 (bench.cpp:87-91, :153-159: apply_RBDL, MinPixRBDL = 0.4,
+// 3 repeats, rbdl.csv) runs the RBDL-equivalent Levenberg-Marquardt IK of lrm_rbdl_equiv_cpu: RBDL itself is
+// an external, unpinned dependency that is absent here -- a timing baseline, parity unpinned.
 //
-//   lrm_bench [outdir] [min_pix] [gpu_repeats] [cpu_repeats]
+//   lrm_bench [outdir] [min_pix] [gpu_repeats] [cpu_repeats] [rbdl_repeats] [min_pix_rbdl]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,18 +46,21 @@ int main(int argc, char** argv) {
     const float min_pix = argc > 2 ? (float)atof(argv[2]) : 0.04f; // setting_bench.h:9
     const int gpu_rep = argc > 3 ? atoi(argv[3]) : 100;            // SubSamples_GPU
     const int cpu_rep = argc > 4 ? atoi(argv[4]) : 10;             // SubSamples_CPU
+    const int rbdl_rep = argc > 5 ? atoi(argv[5]) : 3;             // SubSamples_RBDL
+    const float min_pix_rbdl = argc > 6 ? (float)atof(argv[6]) : 0.4f; // MinPixRBDL
     const LegDimensions dim = get_M2_leg(0);                       // RobotNumb == 1, settings.h:58
-    const char* files[4] = {"rgpu.csv", "rcpu.csv", "dgpu.csv", "dcpu.csv"};
-    for (int ci = 0; ci < 4; ci++) {
-        const bool gpu = (ci % 2) == 0, reach = ci < 2;
-        const int subsample = gpu ? gpu_rep : cpu_rep;
+    const char* files[5] = {"rgpu.csv", "rcpu.csv", "dgpu.csv", "dcpu.csv", "rbdl.csv"};
+    for (int ci = 0; ci < 5; ci++) {
+        const bool rbdl = ci == 4;
+        const bool gpu = !rbdl && (ci % 2) == 0, reach = rbdl || ci < 2;
+        const int subsample = rbdl ? rbdl_rep : (gpu ? gpu_rep : cpu_rep);
         if (subsample <= 0) continue;
         std::ofstream csv(outdir + "/" + files[ci]);
         if (!csv.is_open()) {
             std::cerr << "Failed to open file." << std::endl;
             return 1;
         }
-        for (float pix = min_pix; pix <= MaxPix; pix *= Spacing) {
+        for (float pix = rbdl ? min_pix_rbdl : min_pix; pix <= MaxPix; pix *= Spacing) {
             Array<float3> target_map = generate3DGrid(arange(XMin, XMax, pix), arange(YMin, YMax, pix),
                                                       arange(XMin, ZMax, pix));
             double last = 0;
@@ -64,8 +68,9 @@ int main(int argc, char** argv) {
                 double duration;
                 if (reach) {
                     Array<bool> out{target_map.length, new bool[target_map.length]};
-                    duration = gpu ? apply_kernel(target_map, dim, reachability_global_kernel, out)
-                                   : apply_reach_cpu(target_map, dim, out);
+                    duration = rbdl ? apply_RBDL(target_map, dim, out)
+                               : gpu ? apply_kernel(target_map, dim, reachability_global_kernel, out)
+                                     : apply_reach_cpu(target_map, dim, out);
                     delete[] out.elements;
                 } else {
                     Array<float3> out{target_map.length, new float3[target_map.length]};

@@ -190,3 +190,21 @@ def test_pair_bounding_sphere_contains_every_reachable_pair(lrm, oracle):
         reachable_seen += int(hit.sum())
         assert r2 < 0.75 * (float(leg[1]) + float(leg[3]) + float(leg[4]) + float(leg[5]) + 1) ** 2 or float(leg[3]) <= 0
     assert reachable_seen > 5000
+
+
+def test_rbdl_equivalent_baseline(lrm):
+    """lrm_rbdl_equiv_cpu = apply_RBDL's work (rbdl_benchmark.cpp:18-111) restated: PARITY UNPINNED (RBDL is absent
+    and unpinned), so only sanity is checked: the chain has no joint limits, so nothing beyond its stretched length
+    targets well inside its shell mostly converge within the 10 steps x 5 starts, and the call reports a time.
+    (RBDL's second stopping rule, |dq| < step_tol, also "converges" on an unreachable target when the error is
+    orthogonal to the Jacobian's range -- the stretched leg pointing at it: `valid` is not reachability.)"""
+    pts = random_cloud(20000, seed=4)
+    leg = lrm.get_M2_leg(0.0)
+    ok, ms = lrm.apply_rbdl_equiv(pts, leg)
+    assert ms > 0 and ok.dtype == np.uint8 and set(np.unique(ok)) <= {0, 1}
+    # tip = (body,0,0) + Rz(q0)[(coxa,0,0) + ...]: |tip - (body,0,0)| <= coxa + femur + tibia
+    d = np.linalg.norm(pts - np.array([leg[1], 0, 0], np.float32), axis=1)
+    reach = leg[3] + leg[4] + leg[5]
+    assert ok[d > reach + 1e-3].mean() < 0.05
+    inside = (d < 0.8 * reach) & (d > 0.5 * reach)
+    assert ok[inside].mean() > 0.5

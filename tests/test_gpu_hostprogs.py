@@ -57,13 +57,40 @@ def test_soa_host_entry_points(lrm, oracle):
 def test_bench_harness_writes_reference_csv_format(tmp_path):
     """bench.cpp:164-171 rows `N;ns_per_point`, four files, grid sizes of the committed sweep
     (x in [-100,601], y = 0, z in [-100,51] at pitch min_pix * 2^k <= 50)."""
-    subprocess.run([_built("lrm_bench"), str(tmp_path), "3.2", "3", "1"], check=True, capture_output=True)
-    for name, reps in (("rgpu.csv", 3), ("rcpu.csv", 1), ("dgpu.csv", 3), ("dcpu.csv", 1)):
+    subprocess.run([_built("lrm_bench"), str(tmp_path), "3.2", "3", "1", "2", "6.4"], check=True, capture_output=True)
+    # compute index 4 (bench.cpp:87-91): the RBDL-equivalent IK, own minimum pitch (MinPixRBDL), rbdl.csv
+    for name, reps, grids in (("rgpu.csv", 3, 4), ("rcpu.csv", 1, 4), ("dgpu.csv", 3, 4), ("dcpu.csv", 1, 4), ("rbdl.csv", 2, 3)):
         rows = [l.split(";") for l in open(tmp_path / name).read().split()]
         sizes = [int(r[0]) for r in rows]
         assert all(float(r[1]) > 0 for r in rows)
-        # pitches 3.2, 6.4, 12.8, 25.6 -> 4 grids
-        assert len(rows) == 4 * reps
+        # pitches 3.2, 6.4, 12.8, 25.6 -> 4 grids (3 from 6.4)
+        assert len(rows) == grids * reps
+        if name == "rbdl.csv":
+            continue
         nx = lambda p: len(np.arange(-100, 601 + 1e-6, p))
         # float accumulation in bench.cpp's arange may differ by one sample from numpy's: allow it
         assert abs(sizes[0] - nx(3.2) * len(np.arange(-100, 51 + 1e-6, 3.2))) <= nx(3.2) + 50
+
+
+def test_cpp_mirror_robot_full_struct_and_apply_oct(tmp_path, lrm):
+    """host/sweep_main.cpp calls robot_full_struct(...) and apply_oct(...) of include/lrm_compat.hpp (the
+    reference's signatures, several_leg.cu.h:12-14, several_leg_octree.cu.h:4) on .bin files; the ctypes path
+    (lrm_positionability with the reference's 45 orientations and culls, lrm_apply_oct with default settings)
+    must give the same accepted bodies / leaf centres."""
+    from lrm_amd import workloads
+    ground = workloads.terrain(n_side=64, seed=5)
+    bodies = workloads.body_lattice(ground, 1500, seed=6)
+    for stem, arr in (("body", bodies), ("target", ground)):
+        for k, c in enumerate("xyz"):
+            np.ascontiguousarray(arr[:, k]).tofile(tmp_path / f"{stem}_{c}.bin")
+    out = subprocess.run([_built("lrm_sweep"), str(tmp_path), "1", "4"], check=True, capture_output=True, text=True)
+    assert "robot_full_struct:" in out.stdout and "apply_oct:" in out.stdout
+    legs = workloads.hexapod(lrm.get_M2_leg, 4)
+    want_mask, _ = lrm.positionability(bodies, ground, legs, workloads.reference_sweep_quats(), reference_culls=True)
+    got = np.stack([np.fromfile(tmp_path / f"accepted_{c}.bin", np.float32) for c in "xyz"], -1)
+    counts = np.fromfile(tmp_path / "accepted_count.bin", np.int32)
+    assert np.array_equal(got.view(np.uint32), bodies[want_mask != 0].view(np.uint32))
+    assert len(counts) == len(got) and (counts == 3).all()  # several_leg.cu:868
+    want_oct, _ = lrm.apply_oct(ground, legs[0])
+    got_oct = np.stack([np.fromfile(tmp_path / f"oct_{c}.bin", np.float32) for c in "xyz"], -1)
+    assert np.array_equal(got_oct.view(np.uint32), want_oct.view(np.uint32))
