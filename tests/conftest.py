@@ -42,7 +42,12 @@ def lrm():
 
 def golden_cases(prefix=""):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    return [n for n in names if n != "legs" and n.startswith(prefix)]
+    return [n for n in names if n != "legs" and not n.startswith("terrain") and n.startswith(prefix)]
+
+
+def reference_terrain():
+    """The reference's own terrain cloud and near-ground body lattice (tests/golden/make_terrain.py)."""
+    return dict(np.load(os.path.join(GOLDEN, "terrain_ground.npz")))
 
 
 def load_case(name):

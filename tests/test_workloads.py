@@ -37,6 +37,35 @@ def test_terrain_statistics_and_determinism():
     assert clearance.min() > -1e-3 and clearance.max() < 350 + 1e-3
 
 
+def test_reference_terrain_fixture_pins():
+    """tests/golden/terrain_ground.npz holds the OUTPUT of the reference's own maps.py (made by
+    tests/golden/make_terrain.py in the build container): the pins SURVEY.md section 8(c) lists."""
+    import zlib
+    from conftest import reference_terrain
+    t = reference_terrain()
+    g = t["ground"]
+    assert g.shape == (65536, 3) and g.dtype == np.float32
+    assert (g[:, 0].min(), g[:, 0].max(), g[:, 1].min(), g[:, 1].max()) == (-2000, 2000, -6000, 2000)
+    assert abs(g[:, 2].min() - -2805.0) < 0.5 and abs(g[:, 2].max() - 1025.0) < 0.5
+    assert abs(float(g[1000, 2]) - -25.3596) < 1e-4
+    assert zlib.crc32(g.tobytes()) == 1234698559
+    b = t["bodies"]
+    assert b.shape == (89600, 3) and b.dtype == np.float32 and zlib.crc32(b.tobytes()) == 2829093085
+    # before.py:24-37: 50 mm lattice over the bounding box, z up to max + 350
+    assert (len(t["lattice_x"]), len(t["lattice_y"]), len(t["lattice_z"])) == (80, 160, 84)
+    assert np.allclose(np.diff(t["lattice_x"]), 50) and np.allclose(np.diff(t["lattice_z"]), 50, atol=1e-3)
+    # the bodies are lattice nodes standing 0..350 mm above the nearest ground sample
+    side = 256
+    ix = np.clip(np.rint((b[:, 0] + 2000) / 4000 * (side - 1)).astype(int), 0, side - 1)
+    iy = np.clip(np.rint((b[:, 1] + 6000) / 8000 * (side - 1)).astype(int), 0, side - 1)
+    clearance = b[:, 2] - g[:, 2].reshape(side, side)[iy, ix]
+    assert clearance.min() >= -1e-3 and clearance.max() <= 350 + 1e-3
+    # this repository's own generator (scale-out sizes) keeps the same footprint and relief statistics
+    from lrm_amd import workloads
+    own = workloads.terrain(256)
+    assert abs(own[:, 2].std() - g[:, 2].std()) < 0.15 * g[:, 2].std()
+
+
 def test_reference_sweep_quaternions():
     from lrm_amd import workloads
     q = workloads.reference_sweep_quats()
