@@ -180,7 +180,9 @@ int lrm_reach_any_dev(const float* bx, const float* by, const float* bz, size_t 
  * EVERY leg (limits rotated per orientation, bodies and targets rotated by the quaternion) has a
  * reachable target.  reference_culls != 0 additionally applies multi_rot_estimator's culls: the
  * one-time spheres (r = 60 collision, r = 400 far body / far target, :413-502) and the
- * per-orientation cylinder pair of eliminateFarAndColliding (:504-559).  *ms = kernel time. */
+ * per-orientation cylinder pair of eliminateFarAndColliding (:504-559).  reference_culls == 2 applies only the
+ * per-orientation pair: for callers that shard the bodies over several GPUs and evaluate the one-time culls
+ * themselves (the far-target cull depends on ALL surviving bodies; lrm_amd/shard.py).  *ms = kernel time. */
 int lrm_positionability(const float* bodies_aos, size_t nb, const float* targets_aos, size_t nt,
                         const LrmLegDimensions* legs, size_t nlegs, const float* quats,
                         size_t nquat, int reference_culls, uint8_t* body_mask_out, float* ms);

@@ -332,6 +332,6 @@ def positionability(bodies, targets, legs, quats, reference_culls=False):
     out = np.zeros(len(bodies), np.uint8)
     ms = C.c_float(0)
     check(load().lrm_positionability(_ptr(bodies), len(bodies), _ptr(targets), len(targets), _ptr(legs),
-                                     len(legs), _ptr(quats), len(quats), int(bool(reference_culls)), _ptr(out),
+                                     len(legs), _ptr(quats), len(quats), int(reference_culls), _ptr(out),
                                      C.addressof(ms)))
     return out, ms.value

@@ -723,7 +723,7 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
     float total_ms = 0.f;
     HIP_TRY(hipMemset(d_accepted.p, 0, nb), "hipMemset accepted");
 
-    if (reference_culls && nt) {
+    if (reference_culls == 1 && nt) { // 2: the caller has applied the one-time culls (sharded drivers)
         HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
         int rc = lrm_any_in_sphere_dev(B0, B0 + pb, B0 + 2 * pb, nb, T0, T0 + pt, T0 + 2 * pt, nt, 60.f, d_m1.as<uint8_t>(), nullptr);
         if (rc == LRM_OK) rc = lrm_any_in_sphere_dev(B0, B0 + pb, B0 + 2 * pb, nb, T0, T0 + pt, T0 + 2 * pt, nt, 400.f, d_m2.as<uint8_t>(), nullptr);

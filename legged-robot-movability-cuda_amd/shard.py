@@ -68,3 +68,165 @@ def reach_bits_sharded(compute_local_bits, n, group=None):
     import torch.distributed as dist
     lo, hi = shard_bounds(n, dist.get_world_size(group), dist.get_rank(group))
     return all_gather_bits(compute_local_bits(lo, hi), n, group)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The step loop of `bench.py --gpus N` (and of any caller that streams clouds through the fused kernel):
+# rank r owns shard_bounds(n, world, r) of ONE n-point cloud, a step = local kernel + all-gather of the
+# bit-packed reach mask.  Two word buffers alternate so that the gather of step k (side stream) overlaps the
+# kernel of step k + 1.  The local computation is injected, so the control flow runs under gloo on the CPU.
+# ---------------------------------------------------------------------------------------------------
+class BitsGatherLoop:
+    def __init__(self, n, device="cuda", group=None, host_staging=False):
+        """n: points of the whole cloud.  device: where the word buffers live ("cuda" for RCCL, "cpu" for gloo).
+        host_staging: compute on `device` but gather through host memory (gloo rehearsals of a GPU run)."""
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.n = n
+        self.lo, self.hi = shard_bounds(n, self.world, self.rank)
+        self.per_words = shard_size(n, self.world) // 64
+        self.local_words = (self.hi - self.lo + 63) // 64
+        self.cuda = str(device).startswith("cuda")
+        self.host_staging = host_staging
+        # padded to the common shard size: the tail (ragged last shards) stays 0
+        self.words = [torch.zeros(max(self.per_words, 1), dtype=torch.int64, device=device) for _ in range(2)]
+        gdev = "cpu" if host_staging else device
+        self.gathered = [torch.zeros(max(self.per_words, 1) * self.world, dtype=torch.int64, device=gdev) for _ in range(2)]
+        self.comm_stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self.free = [None, None]  # event after which words[b] may be rewritten
+
+    def step(self, k, compute):
+        """compute(words_view, lo, hi) launches the local evaluation of points [lo, hi) writing words_view
+        (ceil((hi - lo) / 64) int64 words) on the current stream.  Returns the buffer index used."""
+        torch = self.torch
+        b = k & 1
+        if self.cuda and self.free[b] is not None:
+            torch.cuda.current_stream().wait_event(self.free[b])  # the gather of step k - 2 has read words[b]
+        compute(self.words[b][: self.local_words], self.lo, self.hi)
+        if self.world == 1:
+            return b
+        if self.cuda:
+            ready = torch.cuda.Event()
+            ready.record()
+            self.comm_stream.wait_event(ready)
+            with torch.cuda.stream(self.comm_stream):
+                self._gather(b)
+                self.free[b] = torch.cuda.Event()
+                self.free[b].record()
+        else:
+            self._gather(b)
+        return b
+
+    def _gather(self, b):
+        src = self.words[b].cpu() if self.host_staging else self.words[b]
+        self.dist.all_gather_into_tensor(self.gathered[b], src, group=self.group)
+
+    def result(self, b):
+        """The ceil(n / 64) words of the whole cloud from buffer b (synchronises the side stream)."""
+        if self.cuda:
+            self.torch.cuda.synchronize()
+        if self.world == 1:
+            return self.words[b][: (self.n + 63) // 64]
+        return self.gathered[b][: (self.n + 63) // 64]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Positionability on several GPUs (SURVEY.md section 8e).  The reference has none of this (single device).
+# ---------------------------------------------------------------------------------------------------
+class DeviceBackend:
+    """The GPU implementation of the three operations the sharded drivers compose (host arrays in and out)."""
+
+    def any_in_sphere(self, centres, targets, radius):
+        import torch
+        from . import device
+        if len(centres) == 0:
+            return np.zeros(0, np.uint8)
+        c = torch.from_numpy(np.ascontiguousarray(np.asarray(centres, np.float32).T)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(targets, np.float32).T)).cuda()
+        out = device.any_in_sphere(c[0], c[1], c[2], t[0], t[1], t[2], float(radius))
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    def positionability(self, bodies, targets, legs, quats, culls):
+        from . import _capi
+        if len(bodies) == 0:
+            return np.zeros(0, np.uint8)
+        return _capi.positionability(bodies, targets, legs, quats, reference_culls=culls)[0]
+
+    def reach_any(self, bodies, targets, legs, quat):
+        import torch
+        from . import device
+        b = torch.from_numpy(np.ascontiguousarray(np.asarray(bodies, np.float32).T)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(targets, np.float32).T)).cuda()
+        out, _ = device.reach_any(b[0], b[1], b[2], t[0], t[1], t[2], legs, quat)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+
+def _dist_info(group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_world_size(group), dist.get_rank(group)
+    return None, 1, 0
+
+
+def _comm_device(dist, group):
+    return "cuda" if (dist is not None and dist.get_backend(group) == "nccl") else "cpu"
+
+
+def positionability_sharded(bodies, targets, legs, quats, reference_culls=False, backend=None, group=None):
+    """robot_full_struct's result (lrm_positionability) with the BODIES split over the ranks: every rank holds all
+    targets (1.2 MB for 1e5 points) and all legs, evaluates its contiguous slice of bodies, and the per-body bytes
+    are all-gathered; every rank returns the mask of ALL bodies.
+
+    With reference_culls the one-time culls of multi_rot_estimator (several_leg.cu:413-502) are evaluated here,
+    because eliminateFarTarget keeps a target when ANY surviving body -- of any rank -- is within 400 mm: the
+    per-rank keep masks are combined with all_reduce(MAX) (RCCL has no bitwise OR; max on 0/1 bytes is the same).
+    Without a process group this is the single-process composition of the same steps."""
+    import torch
+    backend = backend or DeviceBackend()
+    dist, world, rank = _dist_info(group)
+    bodies = np.ascontiguousarray(np.asarray(bodies, np.float32).reshape(-1, 3))
+    targets = np.ascontiguousarray(np.asarray(targets, np.float32).reshape(-1, 3))
+    nb = len(bodies)
+    lo, hi = shard_bounds(nb, world, rank)
+    mine = bodies[lo:hi]
+    local = np.zeros(hi - lo, np.uint8)
+    if reference_culls and len(targets):
+        collide = backend.any_in_sphere(mine, targets, 60.0)   # eliminateAlwaysColliding
+        near = backend.any_in_sphere(mine, targets, 400.0)     # eliminateFarBody
+        alive = (collide == 0) & (near != 0)
+        keep = backend.any_in_sphere(targets, mine[alive], 400.0) if alive.any() else np.zeros(len(targets), np.uint8)
+        if dist is not None and world > 1:                      # eliminateFarTarget over ALL ranks' survivors
+            t = torch.from_numpy(np.ascontiguousarray(keep)).to(_comm_device(dist, group))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            keep = t.cpu().numpy()
+        kept = targets[keep != 0]
+        if alive.any():
+            local[alive] = backend.positionability(mine[alive], kept, legs, quats, 2)
+    elif not reference_culls:
+        local = backend.positionability(mine, targets, legs, quats, 0)
+    if dist is None or world == 1:
+        return local
+    out = all_gather_bytes(torch.from_numpy(np.ascontiguousarray(local)).to(_comm_device(dist, group)), nb, group)
+    return out.cpu().numpy()
+
+
+def reach_any_target_sharded(bodies, local_targets, legs, quat=None, backend=None, group=None):
+    """The any-flags of reach_mem_kernel (lrm_reach_any_dev) when the CLOUD is the big side (1e8 targets): every rank
+    holds all bodies and its own slice of the targets; the per-(leg, body) bytes are combined with
+    all_reduce(MAX) and the AND over legs is taken locally.  Returns (out[leg, body], all_legs[body]) on every rank."""
+    import torch
+    backend = backend or DeviceBackend()
+    dist, world, rank = _dist_info(group)
+    legs = np.ascontiguousarray(np.asarray(legs, np.float32).reshape(-1, 14))
+    out = np.ascontiguousarray(backend.reach_any(bodies, local_targets, legs, quat).astype(np.uint8))
+    if dist is not None and world > 1:
+        t = torch.from_numpy(out).to(_comm_device(dist, group))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        out = t.cpu().numpy()
+    return out, out.min(axis=0)
