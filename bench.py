@@ -3,17 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE pass of the fused reach+distance kernel (lrm_reach_dist_bits_dev: reach mask
-as bytes and ballot bit words + 3-component distance field) over one synthetic cloud that is
-already resident in HBM as SoA float32.  At N=1 the cloud is BASELINE.json config 2: 1e7
-uniform-random targets in [-200,700]x[-500,500]x[-500,300] mm (seed 42), M2 leg, identity
-orientation.  For N>1 (one process per GPU, torch.distributed over RCCL) every rank holds its
-own 1e7-point shard (weak scaling) and each step ends with the RCCL all-gather of the
-bit-packed reach mask, issued on a side stream so that it overlaps the next step's kernel.
+A "step" is ONE pass of the fused reach+distance launch (lrm_reach_dist_bits_dev: reach mask as bytes and ballot
+bit words + 3-component distance field) over a synthetic cloud that is already resident in HBM as SoA float32.
 
-value = leg-target evaluations per second over the whole job (all ranks), where one
-evaluation = reachability AND distance vector for one (leg, target) pair.
-Rank 0 prints ONE JSON line.
+  N = 1   BASELINE.json config 2: 1e7 uniform-random targets in [-200,700]x[-500,500]x[-500,300] mm (seed 42),
+          M2 leg, identity orientation.
+  N > 1   BASELINE.json config 4 (north star): ONE 1e8-point cloud (same distribution, seeded per 1e6-point chunk so
+          that a rank generates only its own shard), rank r owns lrm_amd.shard.shard_bounds(1e8, N, r); a step =
+          the fused launch on the shard + the RCCL all-gather of the bit-packed reach mask (side stream,
+          overlapping the next step's kernel).  Strong scaling: the total work is fixed.
+
+The headline runs in LRM_MODE_TOL (the contract of BASELINE.json: reach mask bit-exact, distance field within 1e-5
+relative -- include/lrm.h, tests/tolcheck.py); the bit-exact mode (LRM_MODE_FAST: every float of the distance
+field identical to the reference's host path) is timed next to it and reported under "modes".
+value = leg-target evaluations per second over the whole job, one evaluation = reachability AND distance vector
+of one (leg, target) pair.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -28,81 +32,163 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_EVAL = {"reach": 13, "dist": 24, "reach_dist": 25}
+N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU op issues over 2 cycles
+LO = np.array([-200, -500, -500], np.float32)
+HI = np.array([700, 500, 300], np.float32)
+CHUNK = 1_000_000
 
 
-def measured_traffic(points, mode, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md prescribes); None when no
-    committed measurement matches this workload.  PMC counters cannot be read from inside the
-    timed run, so this is the figure of the latest profiled run of the same command."""
+def committed_profile(points, mode):
+    """Figures that cannot be read inside the timed run (PMC counters need their own rocprofv3 passes): the latest
+    committed profiles/r*_hbm_traffic.json / r*_valu.json recorded for this workload and mode."""
     import glob
+    out = {"traffic": None, "traffic_source": None, "valu_insts_per_eval": None, "valu_source": None}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
         try:
             rec = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if rec.get("points_per_launch") == points and rec.get("mode") == mode and kernel in rec.get("kernels", {}):
-            return rec["kernels"][kernel]["hbm_bytes_per_launch"], os.path.basename(path)
-    return None, None
+        if rec.get("points_per_launch") == points and rec.get("mode") == mode and "step_hbm_bytes" in rec:
+            out["traffic"], out["traffic_source"] = rec["step_hbm_bytes"], os.path.basename(path)
+            break
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("mode") == mode and "valu_insts_per_eval" in rec:
+            out["valu_insts_per_eval"], out["valu_source"] = rec["valu_insts_per_eval"], os.path.basename(path)
+            break
+    return out
 
 
 def make_cloud(n, seed):
+    """config 2: one generator, seed 42 (the cloud the tests and the committed profiles use)"""
     rng = np.random.default_rng(seed)
-    lo = np.array([-200, -500, -500], np.float32)
-    hi = np.array([700, 500, 300], np.float32)
     out = np.empty((3, n), np.float32)
-    chunk = 2_000_000
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        out[:, s:e] = (rng.random((e - s, 3), dtype=np.float32) * (hi - lo) + lo).T
+    for s in range(0, n, 2 * CHUNK):
+        e = min(n, s + 2 * CHUNK)
+        out[:, s:e] = (rng.random((e - s, 3), dtype=np.float32) * (HI - LO) + LO).T
+    return out
+
+
+def make_shard(lo, hi, seed=42):
+    """points [lo, hi) of the chunk-seeded cloud: chunk c = default_rng([seed, c]).random((CHUNK, 3))"""
+    out = np.empty((3, hi - lo), np.float32)
+    c = lo // CHUNK
+    while c * CHUNK < hi:
+        pts = np.random.default_rng([seed, c]).random((CHUNK, 3), dtype=np.float32) * (HI - LO) + LO
+        a, b = max(lo, c * CHUNK), min(hi, (c + 1) * CHUNK)
+        out[:, a - lo:b - lo] = pts[a - c * CHUNK:b - c * CHUNK].T
+        c += 1
     return out
 
 
 def cpu_baseline(sample_points, leg):
-    """Reference host path (oracle/_ref, kind "reference") or the C oracle (kind "port") timed
-    on this box's cores: reach loop + distance loop over a bounded sample of the same cloud."""
+    """CPU figures on this box's cores, same cloud, bounded samples.
+    Primary: the product's own CPU entry points lrm_reach_cpu + lrm_dist_cpu (the apply_reach_cpu / apply_dist_cpu
+    drop-ins, cross_compiled.cu:163-181; bit-identical to the reference's host path), one thread as the reference
+    runs them and all cores with a static split.  Beside it: the RBDL-equivalent LM position IK (apply_RBDL's work,
+    parity unpinned) and, where the git-ignored oracle/_ref/libref.so exists, the reference's own host build."""
     from concurrent.futures import ThreadPoolExecutor
-    from oracle import orc
-    if orc.ref_available():
-        impl, kind = orc.Ref(), "reference"
-    else:
-        impl, kind = orc.Oracle(), "port"
+    import lrm_amd
     pts = np.ascontiguousarray(sample_points.T)  # AoS, as the reference's Array<float3>
     n = len(pts)
-    # one thread: the reference's apply_reach_cpu/apply_dist_cpu are single-threaded
+
+    def both(sl):
+        lrm_amd.apply_reach_cpu(sl, leg)
+        lrm_amd.apply_dist_cpu(sl, leg)
+
     n1 = min(n, 4_000_000)
     t0 = time.perf_counter()
-    impl.reach(pts[:n1], leg)
-    impl.dist(pts[:n1], leg)
+    both(pts[:n1])
     single = n1 / (time.perf_counter() - t0)
     cores = min(os.cpu_count() or 1, 16)
-    parts = np.array_split(np.arange(n), cores)
-
-    def work(idx):
-        sl = pts[idx[0]:idx[-1] + 1]
-        impl.reach(sl, leg)
-        impl.dist(sl, leg)
-
+    parts = [pts[i[0]:i[-1] + 1] for i in np.array_split(np.arange(n), cores)]
     with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL during the C loops
         t0 = time.perf_counter()
-        list(ex.map(work, parts))
+        list(ex.map(both, parts))
         dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "leg-target evaluations/s (reach+dist)", "cores": cores, "kind": kind,
-            "sample": f"first {n} points of the same cloud, reach loop + distance loop, {cores} threads "
-                      f"(static split); single thread on {n1} points: {single:.3e}/s",
-            "single_thread_value": single}
+    out = {"value": n / dt, "unit": "leg-target evaluations/s (reach+dist)", "cores": cores, "kind": "port",
+           "impl": "liblrm.so lrm_reach_cpu + lrm_dist_cpu (the apply_reach_cpu / apply_dist_cpu drop-ins; bit-identical "
+                   "to the reference's host path; NOT the RBDL baseline, which is rbdl_equivalent below)",
+           "sample": f"first {n} points of the same cloud, reach loop + distance loop, {cores} threads (static split); "
+                     f"single thread on {n1} points: {single:.3e}/s",
+           "single_thread_value": single}
+    # apply_RBDL's work (rbdl_benchmark.cpp:18-111), 3 repeats as setting_bench.h:7, on <= 1e5 points
+    nr = min(n, 100_000)
+    times = []
+    for _ in range(3):
+        _, ms = lrm_amd.apply_rbdl_equiv(pts[:nr], leg)
+        times.append(ms)
+    ms = float(np.median(times))
+    out["rbdl_equivalent"] = {
+        "value": nr / (ms * 1e-3), "unit": "targets/s (position IK solved or given up)", "ns_per_point": ms * 1e6 / nr,
+        "cores": 1, "sample": f"first {nr} points, median of 3 repeats",
+        "note": "RBDL-equivalent Levenberg-Marquardt position IK (same chain incl. /400, max_steps 10, <= 5 starts) with "
+                "closed-form kinematics; RBDL itself is an external unpinned dependency that is absent: parity unpinned, "
+                "timing baseline only; published RBDL figure: 14 610 ns/point on an i5-12600K (bdata/pc/rbdl.csv)"}
+    try:
+        from oracle import orc
+        if orc.ref_available():
+            ref = orc.Ref()
+            t0 = time.perf_counter()
+            ref.reach(pts[:n1], leg)
+            ref.dist(pts[:n1], leg)
+            out["reference_host_path"] = {"single_thread_value": n1 / (time.perf_counter() - t0),
+                                          "note": "oracle/_ref/libref.so: the reference's own host sources compiled in the "
+                                                  "build container (git-ignored; absent from a fresh clone)"}
+    except Exception:  # the checker is optional here
+        pass
+    return out
+
+
+def config3_block(torch, lrm_amd):
+    """BASELINE config 3 outside the timed headline: 6-leg positionability, one launch of lrm_reach_any_dev on the
+    reference's own terrain and near-ground body lattice (tests/golden/terrain_ground.npz) in Morton order."""
+    from lrm_amd import workloads
+    path = os.path.join(ROOT, "tests", "golden", "terrain_ground.npz")
+    if os.path.exists(path):
+        t = np.load(path)
+        ground, bodies, src = t["ground"], t["bodies"], "reference maps.py output (tests/golden/terrain_ground.npz)"
+    else:
+        ground = workloads.terrain(256)
+        bodies = workloads.body_lattice(ground, 100_000)
+        src = "lrm_amd.workloads.terrain (own generator)"
+    ground = ground[lrm_amd.morton_order(ground)]
+    bodies = bodies[lrm_amd.morton_order(bodies)]
+    legs = workloads.hexapod(lrm_amd.get_M2_leg, 6)
+    tb = torch.from_numpy(np.ascontiguousarray(bodies.T)).cuda()
+    tt = torch.from_numpy(np.ascontiguousarray(ground.T)).cuda()
+    out = torch.empty((6, len(bodies)), dtype=torch.uint8, device="cuda")
+    alll = torch.empty(len(bodies), dtype=torch.uint8, device="cuda")
+    run = lambda: lrm_amd.device.reach_any(tb[0], tb[1], tb[2], tt[0], tt[1], tt[2], legs, None, out=out, all_legs=alll)
+    for _ in range(30):
+        run()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(50):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 50
+    return {"workload": f"{len(bodies)} body poses x {len(ground)} terrain points x 6 M2 legs, identity orientation, Morton order",
+            "data": src, "ms": ms, "pairs_per_s": float(len(bodies)) * len(ground) * 6 / (ms * 1e-3),
+            "positionable_fraction": float(alll.float().mean().item())}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: the GPU needs ~50 ms of sustained load to reach its steady clocks (20 steps after 3
-    # warm-up steps measure 0.26 ms/step, 500 after 100 measure 0.22); 600 steps are 0.15 s of GPU time
+    # defaults: the GPU needs ~50 ms of sustained load to reach its steady clocks
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--points", type=int, default=10_000_000, help="targets per GPU")
-    ap.add_argument("--mode", choices=["strict", "fast"], default=None)
+    ap.add_argument("--points", type=int, default=None, help="N = 1: targets of the config-2 cloud (default 1e7)")
+    ap.add_argument("--total-points", type=int, default=100_000_000, help="N > 1: points of the one sharded cloud")
+    ap.add_argument("--mode", choices=["tol", "fast", "strict"], default="tol", help="arithmetic mode of the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed secondary figures (other mode, reach/dist only, config 3)")
     ap.add_argument("--precondition-ms", type=float, default=100.0,
                     help="untimed GPU load before the W warm-up steps so that short runs are also measured at the "
                          "steady clocks (the first ~50 ms after idle run ~15 %% slower); 0 disables it")
@@ -110,18 +196,18 @@ def main():
 
     import torch
     import lrm_amd
+    from lrm_amd import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # one process per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices
-    device_index = local_rank % torch.cuda.device_count()
+    device_index = local_rank % torch.cuda.device_count()  # rehearsals with more ranks than GPUs share devices
     torch.cuda.set_device(device_index)
     dist = None
-    # LRM_BENCH_BACKEND=gloo rehearses the multi-rank control flow where RCCL cannot run (several
-    # ranks on one GPU): the bit words then travel through host memory
+    # LRM_BENCH_BACKEND=gloo rehearses the multi-rank control flow where RCCL cannot run (several ranks on one
+    # GPU): the bit words then travel through host memory
     backend = os.environ.get("LRM_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
@@ -131,44 +217,26 @@ def main():
             dist.init_process_group(backend)
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if args.mode:
-        lrm_amd.set_mode(lrm_amd.MODE_FAST if args.mode == "fast" else lrm_amd.MODE_STRICT)
-    mode = "fast" if lrm_amd.get_mode() == lrm_amd.MODE_FAST else "strict"
+    modes = {"tol": lrm_amd.MODE_TOL, "fast": lrm_amd.MODE_FAST, "strict": lrm_amd.MODE_STRICT}
+    lrm_amd.set_mode(modes[args.mode])
 
-    n = args.points
     leg = lrm_amd.get_M2_leg(0.0)
-    host = make_cloud(n, seed=42 + rank)
+    if world == 1:
+        n_total = args.points or 10_000_000
+        loop = shard.BitsGatherLoop(n_total, device="cuda")
+        host = make_cloud(n_total, seed=42)
+    else:
+        n_total = args.total_points
+        loop = shard.BitsGatherLoop(n_total, device="cuda", host_staging=(backend != "nccl"))
+        host = make_shard(loop.lo, loop.hi)
+    n = loop.hi - loop.lo  # this rank's points
     cloud = torch.from_numpy(host).cuda()
     x, y, z = cloud[0], cloud[1], cloud[2]
-    nwords = (n + 63) // 64
-    mask = torch.empty(n, dtype=torch.uint8, device="cuda")
-    field = torch.empty((3, n), dtype=torch.float32, device="cuda")
-    bits = [torch.empty(nwords, dtype=torch.int64, device="cuda") for _ in range(2)]
-    gdev = "cuda" if backend == "nccl" else "cpu"
-    gathered = [torch.empty(nwords * world, dtype=torch.int64, device=gdev) for _ in range(2)] if world > 1 else None
-    comm_stream = torch.cuda.Stream() if world > 1 else None
-    gather_done = [None, None]
+    mask = torch.empty(max(n, 1), dtype=torch.uint8, device="cuda")
+    field = torch.empty((3, max(n, 1)), dtype=torch.float32, device="cuda")
 
-    def step(k, ev=None):
-        b = k & 1
-        if world > 1 and gather_done[b] is not None:
-            torch.cuda.current_stream().wait_event(gather_done[b])  # bits[b] is free again
-        if ev:
-            ev[0].record()
-        lrm_amd.device.reach_dist(x, y, z, leg, None, mask=mask, out=field, bits=bits[b])
-        if ev:
-            ev[1].record()
-        if world > 1:
-            ready = torch.cuda.Event()
-            ready.record()
-            comm_stream.wait_event(ready)
-            with torch.cuda.stream(comm_stream):
-                if backend == "nccl":
-                    dist.all_gather_into_tensor(gathered[b], bits[b])
-                else:  # rehearsal path: through host memory (synchronous)
-                    dist.all_gather_into_tensor(gathered[b], bits[b].cpu())
-                gather_done[b] = torch.cuda.Event()
-                gather_done[b].record()
+    def compute(words, lo, hi):
+        lrm_amd.device.reach_dist(x, y, z, leg, None, mask=mask[:n], out=field[:, :n], bits=words)
 
     def full_sync():
         torch.cuda.synchronize()
@@ -184,27 +252,43 @@ def main():
     import gc
     gc.collect()
     gc.disable()  # a generation-2 collection inside the timed loop costs tens of ms of launch-queue starvation
-    if args.precondition_ms > 0:  # clock conditioning: the same launch, results discarded, before the warm-up
-        t_pre = time.perf_counter()
-        while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
-            for _ in range(20):
-                lrm_amd.device.reach_dist(x, y, z, leg, None, mask=mask, out=field, bits=bits[0])
-            torch.cuda.synchronize()
-    for k in range(args.warmup):
-        step(k)
-    full_sync()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, events[k])
-    full_sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        elapsed = reduce_max(elapsed)
-    gc.enable()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
-    # secondary figures (not part of the timed region): reach-only and distance-only kernels
+    def timed_run(steps, warmup, precondition_ms):
+        if precondition_ms > 0:  # clock conditioning: the same launch, results discarded, before the warm-up
+            t_pre = time.perf_counter()
+            while (time.perf_counter() - t_pre) * 1e3 < precondition_ms:
+                for _ in range(20):
+                    compute(loop.words[0][:loop.local_words], loop.lo, loop.hi)
+                torch.cuda.synchronize()
+        for k in range(warmup):
+            loop.step(k, compute)
+        full_sync()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+        cur = {}
+
+        def compute_timed(words, lo, hi):  # HIP events on the launch stream, around the launch(es) of one step
+            cur["ev"][0].record()
+            compute(words, lo, hi)
+            cur["ev"][1].record()
+
+        t0 = time.perf_counter()
+        for k in range(steps):
+            cur["ev"] = ev[k]
+            loop.step(warmup + k, compute_timed)
+        full_sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            elapsed = reduce_max(elapsed)
+        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    elapsed, kernel_ms = timed_run(args.steps, args.warmup, args.precondition_ms)
+    gc.enable()
+
+    # the gathered words of the last step: every rank holds the mask of the whole cloud
+    last = loop.result((args.warmup + args.steps - 1) & 1)
+    reachable_fraction = float(sum(bin(int(w) & (2**64 - 1)).count("1") for w in last[:4096].cpu().tolist()) / (64 * min(4096, last.numel())))
+
     def time_kernel(fn, reps=100):
         for _ in range(20):
             fn()
@@ -217,25 +301,50 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / reps
 
-    extra = {}
-    if rank == 0:
-        ms_reach = time_kernel(lambda: lrm_amd.device.reach(x, y, z, leg, out=mask, bits=bits[0]))
+    extra, other_modes, configs = {}, {}, {}
+    if rank == 0 and not args.no_extras:
+        words = loop.words[0][:loop.local_words]
+        for name in ("tol", "fast"):  # the other arithmetic mode, same launch, untimed region
+            if name == args.mode:
+                continue
+            lrm_amd.set_mode(modes[name])
+            ms = time_kernel(lambda: compute(words, loop.lo, loop.hi), reps=200)
+            other_modes[name] = {"kernel_ms": ms, "evals_per_s_per_gpu": n / (ms * 1e-3),
+                                 "roofline_frac": BYTES_PER_EVAL["reach_dist"] * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        lrm_amd.set_mode(modes[args.mode])
+        ms_reach = time_kernel(lambda: lrm_amd.device.reach(x, y, z, leg, out=mask[:n], bits=words))
         valid = torch.empty(n, dtype=torch.uint8, device="cuda")
-        ms_dist = time_kernel(lambda: lrm_amd.device.dist(x, y, z, leg, out=field, valid=valid))
+        ms_dist = time_kernel(lambda: lrm_amd.device.dist(x, y, z, leg, out=field[:, :n], valid=valid))
         extra = {
             "reach_only": {"evals_per_s": n / (ms_reach * 1e-3), "ms": ms_reach,
-                           "hbm_GBs": BYTES_PER_EVAL["reach"] * n / (ms_reach * 1e-3) / 1e9},
+                           "hbm_GBs": BYTES_PER_EVAL["reach"] * n / (ms_reach * 1e-3) / 1e9,
+                           "roofline_frac": BYTES_PER_EVAL["reach"] * n / (ms_reach * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "dist_only": {"evals_per_s": n / (ms_dist * 1e-3), "ms": ms_dist,
                           "hbm_GBs": BYTES_PER_EVAL["dist"] * n / (ms_dist * 1e-3) / 1e9},
         }
+        if world == 1:
+            configs["c3_positionability"] = config3_block(torch, lrm_amd)
     if world > 1:
         dist.barrier()
 
     if rank == 0:
-        total_evals = float(n) * world * args.steps
+        total_evals = float(n_total) * args.steps
         achieved = BYTES_PER_EVAL["reach_dist"] * n / (kernel_ms * 1e-3) / 1e9
-        kname = "dist_soa_kernel<2, true>" if mode == "fast" else "dist_soa_kernel<2, false>"
-        traffic, traffic_src = measured_traffic(n, mode, kname)
+        kname = {"tol": "dist_tol_kernel<2> + tol_fixup_kernel<2> (one step = both launches)",
+                 "fast": "dist_soa_kernel<2, true>", "strict": "dist_soa_kernel<2, false>"}[args.mode]
+        prof = committed_profile(n, args.mode)
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": prof["traffic"], "traffic_source": prof["traffic_source"],
+            "kernel": kname + " (fused reach+distance)", "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_eval": BYTES_PER_EVAL["reach_dist"],
+            "algorithmic_bytes_per_launch": BYTES_PER_EVAL["reach_dist"] * n,
+        }
+        if prof["valu_insts_per_eval"]:
+            # the kernel is VALU-issue bound: its own floor = wave-instructions / SIMDs x 2 cycles (full-rate class)
+            floor_ms = prof["valu_insts_per_eval"] * n / 64.0 / N_SIMD * 2.0 / CLOCK_HZ * 1e3
+            roofline.update({"valu_insts_per_eval": prof["valu_insts_per_eval"], "valu_source": prof["valu_source"],
+                             "valu_floor_ms": floor_ms, "frac_valu": floor_ms / kernel_ms})
         line = {
             "metric": "leg-target evaluations/sec (reach+dist)",
             "value": total_evals / elapsed,
@@ -246,25 +355,27 @@ def main():
             "precondition_ms": args.precondition_ms,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE config 2: single M2 leg, reach+distance on {n} uniform-random 3-D targets "
-                            f"per GPU (seed 42+rank), identity orientation, SoA resident in HBM",
-                "points_per_gpu": n, "mode": mode,
+                "workload": (f"BASELINE config 2: single M2 leg, reach+distance on {n_total} uniform-random 3-D targets (seed 42), "
+                             f"identity orientation, SoA resident in HBM") if world == 1 else
+                            (f"BASELINE config 4: single M2 leg, reach+distance on ONE cloud of {n_total} uniform-random 3-D targets "
+                             f"(chunk-seeded), sharded contiguously over {world} GPUs ({n} points on rank 0), SoA resident in HBM"),
+                "points_total": n_total, "points_per_gpu": n, "mode": args.mode,
+                "mode_contract": {"tol": "reach mask bit-exact, distance within 1e-5 of max(|d|, |p|/8) (BASELINE contract tolerance)",
+                                  "fast": "mask and every float of the distance field bit-identical to the reference's host path",
+                                  "strict": "as fast, reference operation order"}[args.mode],
                 "exchange": "none" if world == 1 else f"{'RCCL' if backend == 'nccl' else backend} all-gather of the "
                                                          "bit-packed reach mask per step, overlapped on a side stream",
+                "reachable_fraction_sampled": reachable_fraction,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": kname + " (fused reach+distance)", "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_eval": BYTES_PER_EVAL["reach_dist"],
-                "algorithmic_bytes_per_launch": BYTES_PER_EVAL["reach_dist"] * n,
-            },
+            "roofline": roofline,
+            "modes": other_modes,
             "kernels": extra,
+            "configs": configs,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host, leg)
