@@ -257,6 +257,11 @@ int lrm_dbg_fast_host(const float* xyz_aos, size_t n, const LrmLegDimensions* le
  * outputs are final).  Fails with LRM_EINVAL for a leg the mode does not support. */
 int lrm_dbg_tol_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                      uint8_t* mask_out, float* dxyz_aos_out, uint32_t* doubt_out);
+/* As lrm_dbg_tol_host with the mode's plane table (csrc/lrm_tolgrid.cpp) in place of the full plane evaluation:
+ * doubt bit 0x100 = the table holds no answer for a candidate of this point (the GPU path then evaluates the
+ * point in full); *n_fine_out (may be NULL) = refined cells of the table. */
+int lrm_dbg_tolgrid_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+                         uint8_t* mask_out, float* dxyz_aos_out, uint32_t* doubt_out, uint32_t* n_fine_out);
 /* 1 if (leg, quat) is eligible for LRM_MODE_TOL, else 0 */
 int lrm_dbg_tol_ok(const LrmLegDimensions* leg, const float* quat);
 /* The per-leg bounding sphere the pair kernels use to skip batches of footholds:

@@ -81,6 +81,7 @@ def load():
         "lrm_dbg_fused_reach_host": [vp, sz, vp, vp, vp, vp],
         "lrm_dbg_tol_host": [vp, sz, vp, vp, vp, vp, vp],
         "lrm_dbg_tol_ok": [vp, vp],
+        "lrm_dbg_tolgrid_host": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_pair_sphere": [vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
         "lrm_dbg_exact_math_dev": [vp, vp, sz, vp, vp, vp, vp],
@@ -300,6 +301,17 @@ def dbg_tol_host(xyz, leg, quat=None):
     check(load().lrm_dbg_tol_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d),
                                   _ptr(doubt)))
     return mask, d, doubt
+
+
+def dbg_tolgrid_host(xyz, leg, quat=None):
+    """Tolerance mode through its plane table on the host -> (mask, dist, doubt bits, refined cells)."""
+    xyz = _f32(xyz, (-1, 3))
+    n = len(xyz)
+    mask, d, doubt = np.zeros(n, np.uint8), np.zeros_like(xyz), np.zeros(n, np.uint32)
+    nf = C.c_uint32(0)
+    check(load().lrm_dbg_tolgrid_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d),
+                                      _ptr(doubt), C.addressof(nf)))
+    return mask, d, doubt, int(nf.value)
 
 
 def dbg_tol_ok(leg, quat=None):

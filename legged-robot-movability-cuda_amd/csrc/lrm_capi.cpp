@@ -14,6 +14,9 @@
 #include "lrm_point.h"
 #include "lrm_point_fast.h"
 #include "lrm_point_tol.h"
+#ifndef LRM_TOLGRID_MAX_FINE
+#define LRM_TOLGRID_MAX_FINE 1800 // refined cells at most: 32 KB coarse + 28 KB fine + the circle tables stay under 64 KB of LDS
+#endif
 
 namespace {
 
@@ -44,42 +47,86 @@ struct TolKey {
     float v[18];
     bool operator<(const TolKey& o) const { return std::memcmp(v, o.v, sizeof v) < 0; }
 };
-std::map<TolKey, LrmTolLeg> g_tol_cache;
-const LrmTolLeg& tol_leg(const LrmLegDimensions& leg, const float* quat, const LrmCompiledLeg& L) {
+struct TolEntry {
+    LrmTolLeg tl;
+    std::vector<uint8_t> grid;     // the plane table (lrm_build_tol_grid), built on first use
+    std::map<int, uint8_t*> dev;   // its device copies, by device ordinal
+};
+std::map<TolKey, TolEntry> g_tol_cache;
+TolEntry& tol_entry(const LrmLegDimensions& leg, const float* quat, const LrmCompiledLeg& L) {
     TolKey k;
     std::memcpy(k.v, &leg, 14 * sizeof(float));
     std::memcpy(k.v + 14, quat, 4 * sizeof(float));
     auto it = g_tol_cache.find(k);
     if (it != g_tol_cache.end()) return it->second;
-    if (g_tol_cache.size() >= 64) g_tol_cache.clear();
-    LrmTolLeg t;
-    lrm_compile_tol(L, &t);
-    return g_tol_cache.emplace(k, t).first->second;
+    if (g_tol_cache.size() >= 64) { // a sweep over many orientations: start over (device copies are released)
+        for (auto& e : g_tol_cache)
+            for (auto& d : e.second.dev) (void)hipFree(d.second);
+        g_tol_cache.clear();
+    }
+    TolEntry& e = g_tol_cache[k];
+    lrm_compile_tol(L, &e.tl);
+    return e;
 }
-// Device workspace of the doubt queue (fixed size, rewritten by every call), one per (device, stream) in use.
-std::map<std::pair<int, void*>, uint32_t*> g_tol_ws;
-int tol_workspace(void* stream, uint32_t** out) {
+// Device workspace of the doubt queues (rewritten by every call), one per (device, stream) in use, grown on demand.
+struct TolWorkspace {
+    uint32_t* p = nullptr;
+    size_t words = 0;
+};
+std::map<std::pair<int, void*>, TolWorkspace> g_tol_ws;
+int tol_workspace(size_t words, void* stream, uint32_t** out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
-    uint32_t*& w = g_tol_ws[std::make_pair(dev, stream)];
-    if (!w) {
+    TolWorkspace& w = g_tol_ws[std::make_pair(dev, stream)];
+    if (words > w.words) {
+        if (w.p) (void)hipFree(w.p); // synchronises with whatever still uses it
+        w.p = nullptr;
+        w.words = 0;
         void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, lrm_tol_queue_words() * sizeof(uint32_t)), "hipMalloc tolerance-mode queue");
-        w = static_cast<uint32_t*>(p);
+        const size_t want = words + words / 4;
+        HIP_TRY(hipMalloc(&p, want * sizeof(uint32_t)), "hipMalloc tolerance-mode queues");
+        w.p = static_cast<uint32_t*>(p);
+        w.words = want;
     }
-    *out = w;
+    *out = w.p;
     return LRM_OK;
 }
+#ifndef LRM_TOLGRID_MIN_POINTS
+#define LRM_TOLGRID_MIN_POINTS 500000 // below: staging the table in every workgroup's LDS costs more than it saves
+#endif
 
 // distance / fused launch of the SoA kernels in the current mode. op: 1 distance, 2 reach + distance
 int launch_dist_mode(int op, const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions& leg,
                      const float* quat, const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                      float* dz, void* stream) {
     if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xffffffffull) {
-        const LrmTolLeg& TL = tol_leg(leg, quat, L);
+        TolEntry& E = tol_entry(leg, quat, L);
+        const LrmTolLeg& TL = E.tl;
+        if (TL.tol_ok && n >= (size_t)LRM_TOLGRID_MIN_POINTS) {
+            // plane-table variant: table on the host once per (leg, orientation), one device copy per GPU
+            if (E.grid.empty()) lrm_build_tol_grid(TL, LRM_TOLGRID_MAX_FINE, &E.grid);
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+            uint8_t*& gd = E.dev[dev];
+            if (!gd) {
+                void* p = nullptr;
+                HIP_TRY(hipMalloc(&p, E.grid.size()), "hipMalloc plane table");
+                gd = static_cast<uint8_t*>(p);
+                HIP_TRY(hipMemcpy(gd, E.grid.data(), E.grid.size(), hipMemcpyHostToDevice), "hipMemcpy plane table");
+            }
+            uint32_t blocks = 0, seg_cap = 0;
+            size_t words = 0;
+            lrm_tolgrid_plan(n, E.grid.size(), &blocks, &seg_cap, &words);
+            uint32_t* w = nullptr;
+            const int rc = tol_workspace(words, stream, &w);
+            if (rc != LRM_OK) return rc;
+            HIP_TRY(lrm_launch_dist_tolgrid(op, x, y, z, n, L, TL, gd, E.grid.size(), mask, bits, dx, dy, dz, w, (hipStream_t)stream),
+                    "tolerance-mode (plane table) launch");
+            return LRM_OK;
+        }
         if (TL.tol_ok) {
             uint32_t* w = nullptr;
-            const int rc = tol_workspace(stream, &w);
+            const int rc = tol_workspace(lrm_tol_queue_words(), stream, &w);
             if (rc != LRM_OK) return rc;
             HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, (hipStream_t)stream),
                     "tolerance-mode launch");
@@ -640,6 +687,35 @@ int lrm_dbg_tol_host(const float* xyz, size_t n, const LrmLegDimensions* leg, co
         LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         uint32_t doubt = 0;
         mask_out[i] = lrm_dist_tol(TL, T, p, doubt);
+        dxyz_out[3 * i] = p.x;
+        dxyz_out[3 * i + 1] = p.y;
+        dxyz_out[3 * i + 2] = p.z;
+        doubt_out[i] = doubt;
+    }
+    return LRM_OK;
+}
+// as lrm_dbg_tol_host with the plane table in place of the full plane evaluation; doubt bit 0x100 = a candidate's
+// cell carries no answer (the GPU then runs the full evaluation for the point); *n_fine_out = refined cells
+int lrm_dbg_tolgrid_host(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
+                         float* dxyz_out, uint32_t* doubt_out, uint32_t* n_fine_out) {
+    if (!leg || (n && (!xyz || !mask_out || !dxyz_out || !doubt_out))) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    LrmTolLeg TL;
+    lrm_compile_tol(L, &TL);
+    if (!TL.tol_ok) return fail(LRM_EINVAL, "leg not eligible for the tolerance mode");
+    std::vector<uint8_t> grid;
+    const size_t n_fine = lrm_build_tol_grid(TL, LRM_TOLGRID_MAX_FINE, &grid);
+    if (n_fine_out) *n_fine_out = (uint32_t)n_fine;
+    const LrmTolGridHeader* hd = reinterpret_cast<const LrmTolGridHeader*>(grid.data());
+    const uint16_t* coarse = reinterpret_cast<const uint16_t*>(grid.data() + sizeof(LrmTolGridHeader));
+    const uint8_t* fine = grid.data() + sizeof(LrmTolGridHeader) + (size_t)LRM_TG_N * LRM_TG_N * 2;
+    const LrmTolTables T{&TL.circ[0][0], &TL.feat[0]};
+    const LrmTolGridView G{coarse, fine, hd->band_max};
+    for (size_t i = 0; i < n; i++) {
+        LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        uint32_t doubt = 0;
+        mask_out[i] = lrm_dist_tolgrid(TL, T, G, p, doubt);
         dxyz_out[3 * i] = p.x;
         dxyz_out[3 * i + 1] = p.y;
         dxyz_out[3 * i + 2] = p.z;

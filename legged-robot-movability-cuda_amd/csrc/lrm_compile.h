@@ -1,5 +1,8 @@
 // lrm_compile.h -- host side: (LegDimensions, quaternion) -> LrmCompiledLeg.
 #pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
 #include "lrm_types.h"
 
 // apply_leg_rotation != 0: the tibia limits are first rotated by the pitch of the body
@@ -21,3 +24,7 @@ void lrm_host_leg_factory(float azimut, float body2coxa, float coxa_pitch_deg, f
 // (the valid part of some circle is not one arc, a clamp-validity boundary grazes instead of crossing,
 // the leg is not eligible for the filters at all): callers then use LRM_MODE_FAST for that leg.
 void lrm_compile_tol(const LrmCompiledLeg& L, LrmTolLeg* out);
+
+// The plane table of the tolerance mode (lrm_types.h: LrmTolGridHeader | uint16 coarse[LRM_TG_N^2] | uint8 fine[16 n_fine])
+// for an eligible leg; at most max_fine coarse cells are refined.  Returns n_fine.
+size_t lrm_build_tol_grid(const LrmTolLeg& L, size_t max_fine, std::vector<uint8_t>* out);

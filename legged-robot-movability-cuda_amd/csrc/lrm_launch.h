@@ -17,6 +17,13 @@ size_t lrm_tol_queue_words(void);
 hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz,
                                uint32_t* workspace, hipStream_t st);
+// Plane-table variant of LRM_MODE_TOL (three launches on `st`).  grid_dev: device copy of the table built by
+// lrm_build_tol_grid (grid_bytes bytes).  lrm_tolgrid_plan gives the launch geometry and the uint32 words of
+// device workspace the call needs (rewritten by every call).
+void lrm_tolgrid_plan(size_t n, size_t grid_bytes, uint32_t* blocks_out, uint32_t* seg_cap_out, size_t* workspace_words_out);
+hipError_t lrm_launch_dist_tolgrid(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
+                                   const LrmTolLeg& TL, const uint8_t* grid_dev, size_t grid_bytes, uint8_t* mask,
+                                   uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace, hipStream_t st);
 hipError_t lrm_launch_reach_aos(const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask, bool fast,
                                 hipStream_t st);
 hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask,

@@ -71,6 +71,7 @@
 #define LRM_TD_NONE 1u
 #define LRM_TD_LIMIT 1u
 #define LRM_TD_PICK 1u
+#define LRM_TD_AMBIG 1u
 #else
 #define LRM_TD_YAW 1u      // yaw within the band of a sector boundary (limit, limit +- pi/2), or the point near the coxa axis
 #define LRM_TD_REGION 2u   // find_region or point-in-circle decision inside the band
@@ -79,6 +80,7 @@
 #define LRM_TD_NONE 16u    // no clamp target at all (the reference then returns the raw point), or an ill-conditioned clamp
 #define LRM_TD_LIMIT 32u   // yaw-limit alternative ties with the in-plane distance, or the two limits tie
 #define LRM_TD_PICK 64u    // the two yaw candidates tie
+#define LRM_TD_AMBIG 0x100u // plane-table variant: the cell of a candidate's plane point carries no answer (or the band exceeds the table's)
 #endif
 #define LRM_TD_SECOND 0x10000u // statistic only: the second candidate could not be pruned by its lower bound
 
@@ -184,10 +186,58 @@ LRM_HD void lrm_tol_plane(const LrmTolLeg& L, const LrmTolTables T, float u, flo
 #endif
 }
 
+// ---- plane evaluators: the full evaluation above, or the plane table (lrm_types.h, lrm_tolgrid.cpp) ----
+struct LrmTolPlaneFull {
+    const LrmTolLeg& L;
+    LrmTolTables T;
+    LRM_HD void operator()(float u, float z, float band, float tau, float& du, float& dz, bool& valid, uint32_t& doubt) const {
+        lrm_tol_plane(L, T, u, z, band, tau, du, dz, valid, doubt);
+    }
+};
+
+struct LrmTolGridView {
+    const uint16_t* coarse; // [LRM_TG_N * LRM_TG_N]
+    const uint8_t* fine;    // [16 * max(n_fine, 1)]
+    float band_max;
+};
+// code of the cell of plane point (x = abscissa - coxa_length, z), or LRM_TG_AMBIG8.  Branch-free: every lane
+// reads one coarse entry and one fine byte.
+LRM_HD uint32_t lrm_tolgrid_lookup(const LrmTolGridView G, float x, float z) {
+    const float fx = (x + LRM_TG_HALF) * (1.0f / LRM_TG_H), fz = (z + LRM_TG_HALF) * (1.0f / LRM_TG_H);
+    // inside [0, N): also false for nan
+    const bool inside = (fx >= 0.f) && (fx < (float)LRM_TG_N) && (fz >= 0.f) && (fz < (float)LRM_TG_N);
+    const int ix = inside ? (int)fx : 0, iz = inside ? (int)fz : 0;
+    const uint32_t c = G.coarse[iz * LRM_TG_N + ix];
+    const int sx = (int)((fx - (float)ix) * 4.0f) & 3, sz = (int)((fz - (float)iz) * 4.0f) & 3;
+    const bool refined = (c & 0x8000u) && c != LRM_TG_AMBIG16;
+    const uint32_t f = G.fine[refined ? ((c & 0x7fffu) * 16u + (uint32_t)(sz * 4 + sx)) : 0u];
+    const uint32_t code = refined ? f : (c < 64u ? c : (uint32_t)LRM_TG_AMBIG8);
+    return inside ? code : (uint32_t)LRM_TG_AMBIG8;
+}
+struct LrmTolPlaneGrid {
+    const LrmTolLeg& L;
+    LrmTolTables T;
+    LrmTolGridView G;
+    LRM_HD void operator()(float u, float z, float band, float tau, float& du, float& dz, bool& valid, uint32_t& doubt) const {
+        const float x = u - L.coxa_length;
+        const uint32_t code = lrm_tolgrid_lookup(G, x, z);
+        const LrmCircle f = T.feat[code & 31u];
+        const float vx = x - f.x, vy = z - f.y;
+        const float m = __builtin_fmaf(vy, vy, vx * vx);
+        const float s = __builtin_fmaf(-f.r, LRM_FAST_RSQ(m), 1.0f);
+        du = vx * s;
+        dz = vy * s;
+        valid = (code & 32u) != 0u;
+        doubt |= (code == (uint32_t)LRM_TG_AMBIG8 || !(band <= G.band_max)) ? LRM_TD_AMBIG : 0u;
+        (void)tau;
+    }
+};
+
 // distance_global + reachability_global (one_leg_global.cu:74-130) of one body-frame point.
 // p: in = the point, out = the distance vector.  Returns the reach / validity flag (the two coincide whenever
 // no decision is in doubt, see lrm_reach_from_dist).  doubt != 0: the outputs must not be used.
-LRM_HD bool lrm_dist_tol(const LrmTolLeg& L, const LrmTolTables T, LrmVec3& p, uint32_t& doubt) {
+template <class Plane>
+LRM_HD bool lrm_dist_tol_t(const LrmTolLeg& L, const Plane& plane, LrmVec3& p, uint32_t& doubt) {
     const float* a = L.aff;
     const float x = __builtin_fmaf(a[0], p.x, __builtin_fmaf(a[1], p.y, __builtin_fmaf(a[2], p.z, a[3])));
     const float y = __builtin_fmaf(a[4], p.x, __builtin_fmaf(a[5], p.y, __builtin_fmaf(a[6], p.z, a[7])));
@@ -233,7 +283,7 @@ LRM_HD bool lrm_dist_tol(const LrmTolLeg& L, const LrmTolTables T, LrmVec3& p, u
         float du = 0.f, dz = 0.f;
         bool valid = false;
         uint32_t d = 0;
-        lrm_tol_plane(L, T, u, z, band, tau, du, dz, valid, d);
+        plane(u, z, band, tau, du, dz, valid, d);
         // A candidate clamped to a yaw limit whose plane point is valid: the yaw-limit alternative of
         // one_leg.cu:258-274 runs with th = -(limit - sat) = 0, d_limit = |w| < |(du, w, dz)|: the result is
         // the offset from the limit plane alone
@@ -318,4 +368,11 @@ LRM_HD bool lrm_dist_tol(const LrmTolLeg& L, const LrmTolTables T, LrmVec3& p, u
     p.z = __builtin_fmaf(b[6], vx, __builtin_fmaf(b[7], vy, b[8] * vz));
     doubt |= lu;
     return fa || fb;
+}
+
+LRM_HD bool lrm_dist_tol(const LrmTolLeg& L, const LrmTolTables T, LrmVec3& p, uint32_t& doubt) {
+    return lrm_dist_tol_t(L, LrmTolPlaneFull{L, T}, p, doubt);
+}
+LRM_HD bool lrm_dist_tolgrid(const LrmTolLeg& L, const LrmTolTables T, const LrmTolGridView G, LrmVec3& p, uint32_t& doubt) {
+    return lrm_dist_tol_t(L, LrmTolPlaneGrid{L, T, G}, p, doubt);
 }

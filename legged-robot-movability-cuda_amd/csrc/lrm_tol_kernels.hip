@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const uint32_t* __restrict__ queue,
-    const uint32_t* __restrict__ counts, uint32_t nseg, size_t main_stride) {
+    const uint32_t* __restrict__ counts, uint32_t nseg, uint32_t seg_cap, size_t main_stride) {
     __shared__ FixLds s_tab;
     __shared__ uint32_t s_pre[kSegPerWave + 1], s_cnt[kSegPerWave];
     const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kFixLegArg);
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
         uint32_t acc = 0;
         for (int j = 0; j < kSegPerWave; j++) {
             s_pre[j] = acc;
-            acc += s_cnt[j] <= (uint32_t)kSegCap ? s_cnt[j] : 0u; // an overflowed segment is redone as a whole below
+            acc += s_cnt[j] <= seg_cap ? s_cnt[j] : 0u; // an overflowed segment is redone as a whole below
         }
         s_pre[kSegPerWave] = acc;
     }
@@ -181,15 +181,140 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
         int j = 0;
 #pragma unroll
         for (int t = 1; t < kSegPerWave; t++) j += (s_pre[t] <= k) ? 1 : 0; // segments with nothing queued share a prefix
-        redo((size_t)queue[(size_t)(seg0 + j) * kSegCap + (k - s_pre[j])]);
+        redo((size_t)queue[(size_t)(seg0 + j) * seg_cap + (k - s_pre[j])]);
     }
     for (int j = 0; j < kSegPerWave; j++) {
-        if (s_cnt[j] <= (uint32_t)kSegCap) continue; // wave-uniform
+        if (s_cnt[j] <= seg_cap) continue; // wave-uniform (only dist_tol_kernel's fixed-size segments can overflow)
         // every point of workgroup seg0 + j: i = (seg0 + j) * kBlock + t + round * main_stride
         for (size_t base = (size_t)(seg0 + j) * kBlock; base < n; base += main_stride)
             for (int t = lane; t < kBlock; t += kFixBlock)
                 if (base + t < n) redo(base + t);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Plane-table variant (lrm_types.h LrmTolGridHeader, lrm_tolgrid.cpp): three launches.
+//   dist_tolgrid_kernel  every point: prologue + per candidate ONE table lookup (two LDS reads) and the winner's
+//                        clamp.  The table (32 KB coarse + 16 B per refined cell) is staged in LDS per workgroup,
+//                        so the grid is exactly the resident workgroups and strides over the cloud.  A point with
+//                        an unanswered cell or any decision in doubt goes to its WAVE's segment of queue A (slot
+//                        numbers from the wave's own counter: no atomics of any kind).
+//   tol_mid_kernel       one wave per segment of queue A: the full tolerance evaluation (lrm_dist_tol) of those
+//                        points (~7 %), outputs overwritten; ITS doubts go to the wave's segment of queue B.
+//   tol_fixup_kernel     queue B (~0.5 %) through the bit-exact code, as above.
+// Segments hold as many slots as their wave sees points: nothing can overflow.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef LRM_TOLGRID_BLOCK
+#define LRM_TOLGRID_BLOCK 512
+#endif
+#ifndef LRM_TOLGRID_MIN_WAVES
+#define LRM_TOLGRID_MIN_WAVES 6
+#endif
+constexpr int kGridBlock = LRM_TOLGRID_BLOCK;
+
+template <int kOp>
+__global__ __launch_bounds__(kGridBlock, LRM_TOLGRID_MIN_WAVES) void dist_tolgrid_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
+    const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
+    float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ grid, uint32_t grid_bytes,
+    uint32_t* __restrict__ queue_a, uint32_t* __restrict__ counts_a, uint32_t seg_cap) {
+    __shared__ TolLds s_tab;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_grid[]; // coarse | fine (the header stays in global memory)
+    const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
+    {
+        const float* csrc = reinterpret_cast<const float*>(&L.circ[0][0]);
+        const float* fsrc = reinterpret_cast<const float*>(&L.feat[0]);
+        for (int i = threadIdx.x; i < (int)(sizeof(s_tab.circ) / 4); i += kGridBlock) reinterpret_cast<float*>(s_tab.circ)[i] = csrc[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(s_tab.feat) / 4); i += kGridBlock) reinterpret_cast<float*>(s_tab.feat)[i] = fsrc[i];
+        const uint4* gsrc = reinterpret_cast<const uint4*>(grid + sizeof(LrmTolGridHeader));
+        const uint32_t n16 = (grid_bytes - (uint32_t)sizeof(LrmTolGridHeader)) >> 4;
+        for (uint32_t i = threadIdx.x; i < n16; i += kGridBlock) reinterpret_cast<uint4*>(s_grid)[i] = gsrc[i];
+        __syncthreads();
+    }
+    const LrmTolTables T{s_tab.circ, s_tab.feat};
+    const LrmTolGridView G{reinterpret_cast<const uint16_t*>(s_grid), s_grid + (size_t)LRM_TG_N * LRM_TG_N * 2,
+                           reinterpret_cast<const LrmTolGridHeader*>(grid)->band_max};
+    const size_t stride = (size_t)gridDim.x * kGridBlock;
+    const size_t n_pad = (n + 63) & ~(size_t)63;
+    const uint32_t wave = blockIdx.x * (kGridBlock / 64) + (threadIdx.x >> 6);
+    uint32_t* seg = queue_a + (size_t)wave * seg_cap;
+    const int lane = threadIdx.x & 63;
+    uint32_t cnt = 0; // wave-uniform
+    for (size_t i = (size_t)blockIdx.x * kGridBlock + threadIdx.x; i < n_pad; i += stride) {
+        bool m = false;
+        uint32_t doubt = 0;
+        if (i < n) {
+            LrmVec3 p{x[i], y[i], z[i]};
+            m = lrm_dist_tolgrid(L, T, G, p, doubt);
+            doubt &= 0xffffu;
+            dx[i] = p.x;
+            dy[i] = p.y;
+            dz[i] = p.z;
+            if (mask) mask[i] = m;
+        }
+        if (bits) {
+            const uint64_t w = __ballot(m);
+            if (lane == 0) bits[i >> 6] = w;
+        }
+        const uint64_t dm = __ballot(doubt != 0);
+        if (doubt) seg[cnt + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        cnt += (uint32_t)__popcll(dm);
+    }
+    if (lane == 0) counts_a[wave] = cnt;
+}
+
+// one wave per segment of queue A
+template <int kOp>
+__global__ __launch_bounds__(kFixBlock) void tol_mid_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
+    const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
+    float* __restrict__ dy, float* __restrict__ dz, const uint32_t* __restrict__ queue_a,
+    const uint32_t* __restrict__ counts_a, uint32_t* __restrict__ queue_b, uint32_t* __restrict__ counts_b,
+    uint32_t seg_cap) {
+    __shared__ TolLds s_tab;
+    const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
+    const uint32_t total = counts_a[blockIdx.x];
+    const int lane = threadIdx.x;
+    if (total == 0) {
+        if (lane == 0) counts_b[blockIdx.x] = 0;
+        return;
+    }
+    {
+        const float* csrc = reinterpret_cast<const float*>(&L.circ[0][0]);
+        const float* fsrc = reinterpret_cast<const float*>(&L.feat[0]);
+        for (int i = lane; i < (int)(sizeof(s_tab.circ) / 4); i += kFixBlock) reinterpret_cast<float*>(s_tab.circ)[i] = csrc[i];
+        for (int i = lane; i < (int)(sizeof(s_tab.feat) / 4); i += kFixBlock) reinterpret_cast<float*>(s_tab.feat)[i] = fsrc[i];
+        __syncthreads();
+    }
+    const LrmTolTables T{s_tab.circ, s_tab.feat};
+    const uint32_t* seg_a = queue_a + (size_t)blockIdx.x * seg_cap;
+    uint32_t* seg_b = queue_b + (size_t)blockIdx.x * seg_cap;
+    uint32_t cnt = 0;
+    for (uint32_t k0 = 0; k0 < total; k0 += kFixBlock) { // whole wave iterates together (ballot below)
+        const uint32_t k = k0 + lane;
+        uint32_t doubt = 0;
+        size_t i = 0;
+        if (k < total) {
+            i = seg_a[k];
+            LrmVec3 p{x[i], y[i], z[i]};
+            const bool m = lrm_dist_tol(L, T, p, doubt);
+            doubt &= 0xffffu;
+            dx[i] = p.x;
+            dy[i] = p.y;
+            dz[i] = p.z;
+            if (mask) mask[i] = m;
+            if (bits) {
+                unsigned long long* w = reinterpret_cast<unsigned long long*>(bits) + (i >> 6);
+                const unsigned long long bit = 1ull << (i & 63);
+                if (m) atomicOr(w, bit);
+                else atomicAnd(w, ~bit);
+            }
+        }
+        const uint64_t dm = __ballot(doubt != 0);
+        if (doubt) seg_b[cnt + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        cnt += (uint32_t)__popcll(dm);
+    }
+    if (lane == 0) counts_b[blockIdx.x] = cnt;
 }
 
 } // namespace
@@ -211,7 +336,60 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
     const size_t stride = blocks * kBlock;
-    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, stride);
-    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, stride);
+    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    return hipGetLastError();
+}
+
+// ---- plane-table variant ------------------------------------------------------------------------------------
+namespace {
+// resident workgroups of dist_tolgrid_kernel for a table of `lds_bytes` (static + dynamic LDS): 160 KB per CU
+int tolgrid_blocks_per_cu(size_t lds_bytes) {
+    int b = (int)((size_t)160 * 1024 / (lds_bytes + 512)); // LDS is allocated in 512-byte granules
+    const int by_waves = 32 / (kGridBlock / 64);             // 32 waves per CU
+    if (b > by_waves) b = by_waves;
+    const int by_regs = (LRM_TOLGRID_MIN_WAVES * 4) / (kGridBlock / 64);
+    if (b > by_regs && by_regs > 0) b = by_regs;
+    return b < 1 ? 1 : b;
+}
+} // namespace
+
+void lrm_tolgrid_plan(size_t n, size_t grid_bytes, uint32_t* blocks_out, uint32_t* seg_cap_out, size_t* workspace_words_out) {
+    const size_t lds = sizeof(TolLds) + grid_bytes - sizeof(LrmTolGridHeader);
+    size_t blocks = (size_t)256 * tolgrid_blocks_per_cu(lds);
+    const size_t need = (n + kGridBlock - 1) / kGridBlock;
+    if (blocks > need) blocks = need ? need : 1;
+    const size_t stride = blocks * kGridBlock;
+    const size_t iters = (((n + 63) & ~(size_t)63) + stride - 1) / stride;
+    const size_t seg_cap = iters * 64;
+    const size_t waves = blocks * (kGridBlock / 64);
+    *blocks_out = (uint32_t)blocks;
+    *seg_cap_out = (uint32_t)seg_cap;
+    *workspace_words_out = 2 * waves * seg_cap + 2 * waves; // queue A, queue B, counts A, counts B
+}
+
+hipError_t lrm_launch_dist_tolgrid(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
+                                   const LrmTolLeg& TL, const uint8_t* grid_dev, size_t grid_bytes, uint8_t* mask,
+                                   uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace, hipStream_t st) {
+    uint32_t blocks = 0, seg_cap = 0;
+    size_t words = 0;
+    lrm_tolgrid_plan(n, grid_bytes, &blocks, &seg_cap, &words);
+    const size_t waves = (size_t)blocks * (kGridBlock / 64);
+    uint32_t* queue_a = workspace;
+    uint32_t* queue_b = queue_a + waves * seg_cap;
+    uint32_t* counts_a = queue_b + waves * seg_cap;
+    uint32_t* counts_b = counts_a + waves;
+    const size_t dyn = grid_bytes - sizeof(LrmTolGridHeader);
+    if (op == 2) hipLaunchKernelGGL(dist_tolgrid_kernel<2>, dim3(blocks), dim3(kGridBlock), dyn, st, x, y, z, n, TL, mask, bits, dx, dy, dz, grid_dev, (uint32_t)grid_bytes, queue_a, counts_a, seg_cap);
+    else hipLaunchKernelGGL(dist_tolgrid_kernel<1>, dim3(blocks), dim3(kGridBlock), dyn, st, x, y, z, n, TL, mask, bits, dx, dy, dz, grid_dev, (uint32_t)grid_bytes, queue_a, counts_a, seg_cap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (op == 2) hipLaunchKernelGGL(tol_mid_kernel<2>, dim3((unsigned)waves), dim3(kFixBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue_a, counts_a, queue_b, counts_b, seg_cap);
+    else hipLaunchKernelGGL(tol_mid_kernel<1>, dim3((unsigned)waves), dim3(kFixBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue_a, counts_a, queue_b, counts_b, seg_cap);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const unsigned fblocks = (unsigned)((waves + kSegPerWave - 1) / kSegPerWave);
+    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue_b, counts_b, (uint32_t)waves, seg_cap, (size_t)0);
+    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue_b, counts_b, (uint32_t)waves, seg_cap, (size_t)0);
     return hipGetLastError();
 }

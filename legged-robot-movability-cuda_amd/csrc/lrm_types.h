@@ -160,3 +160,25 @@ struct LrmTolLeg {
     int32_t tol_ok;       // 0: this leg must use LRM_MODE_FAST
     float pad_[2];
 };
+
+// ---- plane table of the tolerance mode (lrm_tolgrid.cpp, lrm_point_tol.h) ---------------------------------
+// Which clamp target wins (and whether the point is valid) is piecewise constant over the leg's meridian plane.
+// The table stores that answer per cell of a two-level grid over plane coordinates (x = abscissa - coxa_length, z):
+//   coarse: LRM_TG_N x LRM_TG_N cells of LRM_TG_H mm over [-LRM_TG_HALF, LRM_TG_HALF)^2, one uint16 each:
+//           < 64: the code of the whole cell;  0x8000 | b: refined into the 4 x 4 sub-cells of fine block b;
+//           0xffff: ambiguous and not refined (no room left)
+//   fine:   16 bytes per refined cell (row-major 4 x 4 sub-cells of LRM_TG_H / 4 mm): code, or 0xff = ambiguous
+//   code:   bits 0-4 the winning clamp target (index into LrmTolLeg::feat), bit 5 the validity of the point.
+// A cell carries a code only when EVERY decision of lrm_tol_plane keeps its margin over the whole cell for every
+// point with band <= band_max (Lipschitz bounds, lrm_tolgrid.cpp); anything else is "ambiguous" and is evaluated
+// in full.  Built on the host once per (leg, orientation), resident in device memory, staged in LDS per workgroup.
+#define LRM_TG_N 128
+#define LRM_TG_H 16.0f
+#define LRM_TG_HALF 1024.0f
+#define LRM_TG_AMBIG16 0xffffu
+#define LRM_TG_AMBIG8 0xffu
+struct LrmTolGridHeader {
+    uint32_t n_fine;      // refined cells (16 bytes each)
+    float band_max;       // the table holds for points whose decision band (mm) is at most this
+    uint32_t pad[2];
+};

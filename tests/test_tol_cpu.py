@@ -65,3 +65,25 @@ def test_tol_nonfinite_inputs_are_in_doubt(lrm):
     pts = np.array([[np.nan, 0, 0], [np.inf, 1, 2], [1e30, 1e30, -1e30], [0, 0, 0], [181.0, 0.0, 0.0]], np.float32)
     _, _, doubt = lrm.dbg_tol_host(pts, lrm.get_M2_leg(0.0))
     assert (doubt[:3] != 0).all()
+
+
+@pytest.mark.parametrize("legname,az,q", [("m2", 0.0, QUATS[0]), ("moonbot", np.pi / 3, QUATS[1]), ("m2", -2.0, QUATS[3])])
+def test_tol_plane_table_vs_oracle(lrm, oracle, legname, az, q):
+    """The plane table (csrc/lrm_tolgrid.cpp) replaces the full plane evaluation where a cell's answer is proven
+    constant: every point it resolves (no doubt bit, no 0x100 "unanswered cell") must carry the oracle's mask and a
+    vector inside the tolerance; unanswered points (evaluated in full on the GPU) must stay a small fraction."""
+    leg = lrm.get_M2_leg(az) if legname == "m2" else lrm.get_moonbot_leg(az)
+    pts = random_cloud(200_000, seed=17)
+    m, d, doubt, n_fine = lrm.dbg_tolgrid_host(pts, leg, q)
+    want_d, want_v = oracle.dist(pts, leg, q)
+    sure = (doubt & 0xffff) == 0
+    assert np.array_equal(m[sure], oracle.reach(pts, leg, q)[sure]) and np.array_equal(m[sure], want_v[sure])
+    e = field_error(pts[sure], d[sure], want_d[sure])
+    assert e["metric"].max(initial=0.0) <= TOL
+    assert 0 < n_fine <= 1800
+    assert ((doubt & 0x100) != 0).mean() < 0.12
+    # same answers as the full evaluation wherever both are certain
+    m2, d2, doubt2 = lrm.dbg_tol_host(pts, leg, q)
+    both = sure & ((doubt2 & 0xffff) == 0)
+    assert np.array_equal(m[both], m2[both])
+    assert np.abs(d[both] - d2[both]).max() < 1e-3
