@@ -262,6 +262,9 @@ int lrm_dbg_tol_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg
  * point in full); *n_fine_out (may be NULL) = refined cells of the table. */
 int lrm_dbg_tolgrid_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                          uint8_t* mask_out, float* dxyz_aos_out, uint32_t* doubt_out, uint32_t* n_fine_out);
+/* After a device call that took the plane-table path of LRM_MODE_TOL (>= 5e5 points): points of that call, how
+ * many of them needed the full evaluation, how many the bit-exact code.  Synchronises the device. */
+int lrm_dbg_tol_queue_counts(uint64_t* n_points, uint64_t* n_full, uint64_t* n_exact);
 /* 1 if (leg, quat) is eligible for LRM_MODE_TOL, else 0 */
 int lrm_dbg_tol_ok(const LrmLegDimensions* leg, const float* quat);
 /* The per-leg bounding sphere the pair kernels use to skip batches of footholds:

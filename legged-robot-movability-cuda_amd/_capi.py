@@ -81,6 +81,7 @@ def load():
         "lrm_dbg_fused_reach_host": [vp, sz, vp, vp, vp, vp],
         "lrm_dbg_tol_host": [vp, sz, vp, vp, vp, vp, vp],
         "lrm_dbg_tol_ok": [vp, vp],
+        "lrm_dbg_tol_queue_counts": [vp, vp, vp],
         "lrm_dbg_tolgrid_host": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_pair_sphere": [vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
@@ -312,6 +313,13 @@ def dbg_tolgrid_host(xyz, leg, quat=None):
     check(load().lrm_dbg_tolgrid_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d),
                                       _ptr(doubt), C.addressof(nf)))
     return mask, d, doubt, int(nf.value)
+
+
+def dbg_tol_queue_counts():
+    """(points, sent to the full evaluation, sent to the bit-exact code) of the last plane-table call."""
+    a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    check(load().lrm_dbg_tol_queue_counts(C.addressof(a), C.addressof(b), C.addressof(c)))
+    return int(a.value), int(b.value), int(c.value)
 
 
 def dbg_tol_ok(leg, quat=None):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <map>
@@ -91,6 +92,27 @@ int tol_workspace(size_t words, void* stream, uint32_t** out) {
     *out = w.p;
     return LRM_OK;
 }
+// geometry of the last plane-table call, for lrm_dbg_tol_queue_counts
+struct TolLast {
+    uint32_t* ws = nullptr;
+    size_t waves = 0, seg_cap = 0, n = 0;
+} g_tol_last;
+#ifndef LRM_TOLGRID_BLOCK
+#define LRM_TOLGRID_BLOCK_DEFAULT 512
+#else
+#define LRM_TOLGRID_BLOCK_DEFAULT LRM_TOLGRID_BLOCK
+#endif
+// The plane-table variant is opt-in (environment LRM_TOL_PLANE_TABLE=1, read once): its table kernel runs at 3.2 TB/s
+// (79 us per 1e7 points against 115 us for the plain tolerance kernel), but the 7 % of points its table cannot
+// answer cost 65 us more wherever they are re-evaluated (scattered 4-byte accesses), so end to end it is slower
+// (DESIGN.md section 3).
+bool tol_plane_table_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("LRM_TOL_PLANE_TABLE");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
 #ifndef LRM_TOLGRID_MIN_POINTS
 #define LRM_TOLGRID_MIN_POINTS 500000 // below: staging the table in every workgroup's LDS costs more than it saves
 #endif
@@ -102,7 +124,7 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
     if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xffffffffull) {
         TolEntry& E = tol_entry(leg, quat, L);
         const LrmTolLeg& TL = E.tl;
-        if (TL.tol_ok && n >= (size_t)LRM_TOLGRID_MIN_POINTS) {
+        if (TL.tol_ok && n >= (size_t)LRM_TOLGRID_MIN_POINTS && tol_plane_table_enabled()) {
             // plane-table variant: table on the host once per (leg, orientation), one device copy per GPU
             if (E.grid.empty()) lrm_build_tol_grid(TL, LRM_TOLGRID_MAX_FINE, &E.grid);
             int dev = 0;
@@ -122,6 +144,7 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
             if (rc != LRM_OK) return rc;
             HIP_TRY(lrm_launch_dist_tolgrid(op, x, y, z, n, L, TL, gd, E.grid.size(), mask, bits, dx, dy, dz, w, (hipStream_t)stream),
                     "tolerance-mode (plane table) launch");
+            g_tol_last = TolLast{w, (size_t)blocks * (LRM_TOLGRID_BLOCK_DEFAULT / 64), seg_cap, n};
             return LRM_OK;
         }
         if (TL.tol_ok) {
@@ -721,6 +744,21 @@ int lrm_dbg_tolgrid_host(const float* xyz, size_t n, const LrmLegDimensions* leg
         dxyz_out[3 * i + 2] = p.z;
         doubt_out[i] = doubt;
     }
+    return LRM_OK;
+}
+// After a plane-table call in LRM_MODE_TOL (synchronises the device): how many points went to the full evaluation
+// (queue A) and how many of those on to the bit-exact code (queue B).
+int lrm_dbg_tol_queue_counts(uint64_t* n_points, uint64_t* n_full, uint64_t* n_exact) {
+    if (!g_tol_last.ws || !n_points || !n_full || !n_exact) return fail(LRM_EINVAL, "no plane-table call yet");
+    HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    std::vector<uint32_t> c(2 * g_tol_last.waves);
+    const uint32_t* counts = g_tol_last.ws + 2 * g_tol_last.waves * g_tol_last.seg_cap;
+    HIP_TRY(hipMemcpy(c.data(), counts, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy counts");
+    uint64_t a = 0, b = 0;
+    for (size_t i = 0; i < g_tol_last.waves; i++) { a += c[i]; b += c[g_tol_last.waves + i]; }
+    *n_points = g_tol_last.n;
+    *n_full = a;
+    *n_exact = b;
     return LRM_OK;
 }
 int lrm_dbg_tol_ok(const LrmLegDimensions* leg, const float* quat) {

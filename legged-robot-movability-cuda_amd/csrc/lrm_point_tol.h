@@ -188,6 +188,7 @@ LRM_HD void lrm_tol_plane(const LrmTolLeg& L, const LrmTolTables T, float u, flo
 
 // ---- plane evaluators: the full evaluation above, or the plane table (lrm_types.h, lrm_tolgrid.cpp) ----
 struct LrmTolPlaneFull {
+    static constexpr bool kSkipSame = true; // a wave whose lanes all have one configuration skips the second evaluation
     const LrmTolLeg& L;
     LrmTolTables T;
     LRM_HD void operator()(float u, float z, float band, float tau, float& du, float& dz, bool& valid, uint32_t& doubt) const {
@@ -215,6 +216,7 @@ LRM_HD uint32_t lrm_tolgrid_lookup(const LrmTolGridView G, float x, float z) {
     return inside ? code : (uint32_t)LRM_TG_AMBIG8;
 }
 struct LrmTolPlaneGrid {
+    static constexpr bool kSkipSame = false; // two short lookups: straight-line code lets their LDS reads overlap
     const LrmTolLeg& L;
     LrmTolTables T;
     LrmTolGridView G;
@@ -271,7 +273,7 @@ LRM_HD bool lrm_dist_tol_t(const LrmTolLeg& L, const Plane& plane, LrmVec3& p, u
     bool fa = false, fb = false;
 #pragma unroll LRM_TOL_CAND_UNROLL
     for (int k = 0; k < 2; k++) {
-        if (k && LRM_TOL_ALL(same)) break; // the second candidate is the first one again
+        if (Plane::kSkipSame && k && LRM_TOL_ALL(same)) break; // the second candidate is the first one again
         const uint32_t code = k ? codeF : codeD;
         const bool lim = code >= 2u, mn = code == 3u, neg = code == 1u;
         // rotate the point by -sat: (cos, sin)(sat) = +-(x, y) / r for its own / the opposite meridian plane,

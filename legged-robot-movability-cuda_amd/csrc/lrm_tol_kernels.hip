@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "lrm_launch.h"
 #include "lrm_types.h"
 #define LRM_FRESH(L) lrm_fresh(L)
@@ -118,6 +120,18 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_kernel(
     if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
 }
 
+// Bit i of the ballot words an earlier launch wrote becomes `m`.  Only this lane ever changes that bit, so a plain
+// read decides whether anything has to change; the (rare) change is an atomic on the word, which other lanes patch
+// other bits of.  (Unconditional atomics cost the middle kernel 40 us per 7e5 points.)
+__device__ __forceinline__ void patch_bit(uint64_t* bits, size_t i, bool m) {
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(bits) + (i >> 6);
+    const unsigned long long bit = 1ull << (i & 63);
+    const bool cur = (__builtin_nontemporal_load(w) & bit) != 0ull;
+    if (cur == m) return;
+    if (m) atomicOr(w, bit);
+    else atomicAnd(w, ~bit);
+}
+
 struct FixLds {
     LrmCircle lists[16];
     LrmCompiledLeg::DistCircle dist[16];
@@ -137,6 +151,17 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kFixLegArg);
     const uint32_t seg0 = blockIdx.x * kSegPerWave;
     const int lane = threadIdx.x;
+    // This kernel is a chain of latencies (launch, counts, tables, gather, ~2000 dependent instructions of the exact
+    // code at one wave per SIMD): the table loads (16 bytes per lane and pass) go out first, the counts behind them.
+    static_assert(sizeof(s_tab.lists) % 16 == 0 && sizeof(s_tab.dist) % 16 == 0 && sizeof(s_tab.corners) % 16 == 0, "16-byte staging");
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(&L.lists[0][0]);
+        const uint4* dsrc = reinterpret_cast<const uint4*>(&L.dist_tab[0][0]);
+        const uint4* csrc = reinterpret_cast<const uint4*>(&L.corner_tab[0]);
+        for (int i = lane; i < (int)(sizeof(s_tab.lists) / 16); i += kFixBlock) reinterpret_cast<uint4*>(s_tab.lists)[i] = src[i];
+        for (int i = lane; i < (int)(sizeof(s_tab.dist) / 16); i += kFixBlock) reinterpret_cast<uint4*>(s_tab.dist)[i] = dsrc[i];
+        for (int i = lane; i < (int)(sizeof(s_tab.corners) / 16); i += kFixBlock) reinterpret_cast<uint4*>(s_tab.corners)[i] = csrc[i];
+    }
     if (lane < kSegPerWave) s_cnt[lane] = (seg0 + lane < nseg) ? counts[seg0 + lane] : 0u;
     __syncthreads();
     if (lane == 0) {
@@ -150,14 +175,6 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     uint32_t any = 0;
     for (int j = 0; j < kSegPerWave; j++) any |= s_cnt[j];
     if (any == 0) return; // nothing in doubt in these workgroups (wave-uniform)
-    {
-        const float* src = reinterpret_cast<const float*>(&L.lists[0][0]);
-        const float* dsrc = reinterpret_cast<const float*>(&L.dist_tab[0][0]);
-        const float* csrc = reinterpret_cast<const float*>(&L.corner_tab[0]);
-        for (int i = lane; i < (int)(sizeof(s_tab.lists) / 4); i += kFixBlock) reinterpret_cast<float*>(s_tab.lists)[i] = src[i];
-        for (int i = lane; i < (int)(sizeof(s_tab.dist) / 4); i += kFixBlock) reinterpret_cast<float*>(s_tab.dist)[i] = dsrc[i];
-        for (int i = lane; i < (int)(sizeof(s_tab.corners) / 4); i += kFixBlock) reinterpret_cast<float*>(s_tab.corners)[i] = csrc[i];
-    }
     __syncthreads();
     const LrmDistTables T{s_tab.lists, s_tab.dist, s_tab.corners};
     auto redo = [&](size_t i) {
@@ -169,12 +186,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
         dy[i] = p.y;
         dz[i] = p.z;
         if (mask) mask[i] = m;
-        if (bits) { // one bit of a word the tolerance kernel wrote: distinct addresses, no contention
-            unsigned long long* w = reinterpret_cast<unsigned long long*>(bits) + (i >> 6);
-            const unsigned long long bit = 1ull << (i & 63);
-            if (m) atomicOr(w, bit);
-            else atomicAnd(w, ~bit);
-        }
+        if (bits) patch_bit(bits, i, m);
     };
     const uint32_t total = s_pre[kSegPerWave];
     for (uint32_t k = lane; k < total; k += kFixBlock) {
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
         redo((size_t)queue[(size_t)(seg0 + j) * seg_cap + (k - s_pre[j])]);
     }
     for (int j = 0; j < kSegPerWave; j++) {
-        if (s_cnt[j] <= seg_cap) continue; // wave-uniform (only dist_tol_kernel's fixed-size segments can overflow)
+        if (s_cnt[j] <= seg_cap || main_stride == 0) continue; // wave-uniform (only dist_tol_kernel's fixed-size segments can overflow)
         // every point of workgroup seg0 + j: i = (seg0 + j) * kBlock + t + round * main_stride
         for (size_t base = (size_t)(seg0 + j) * kBlock; base < n; base += main_stride)
             for (int t = lane; t < kBlock; t += kFixBlock)
@@ -204,6 +216,9 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
 //   tol_fixup_kernel     queue B (~0.5 %) through the bit-exact code, as above.
 // Segments hold as many slots as their wave sees points: nothing can overflow.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef LRM_TOLGRID_MERGED
+#define LRM_TOLGRID_MERGED 2 // 2: the full evaluation of the unanswered points runs inside dist_tolgrid_kernel as soon as 64 are queued; 1: at its end; 0: in tol_mid_kernel
+#endif
 #ifndef LRM_TOLGRID_BLOCK
 #define LRM_TOLGRID_BLOCK 512
 #endif
@@ -217,7 +232,8 @@ __global__ __launch_bounds__(kGridBlock, LRM_TOLGRID_MIN_WAVES) void dist_tolgri
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ grid, uint32_t grid_bytes,
-    uint32_t* __restrict__ queue_a, uint32_t* __restrict__ counts_a, uint32_t seg_cap) {
+    uint32_t* __restrict__ queue_a, uint32_t* __restrict__ counts_a, uint32_t* __restrict__ queue_b,
+    uint32_t* __restrict__ counts_b, uint32_t seg_cap) {
     __shared__ TolLds s_tab;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_grid[]; // coarse | fine (the header stays in global memory)
     const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
@@ -240,11 +256,42 @@ __global__ __launch_bounds__(kGridBlock, LRM_TOLGRID_MIN_WAVES) void dist_tolgri
     uint32_t* seg = queue_a + (size_t)wave * seg_cap;
     const int lane = threadIdx.x & 63;
     uint32_t cnt = 0; // wave-uniform
-    for (size_t i = (size_t)blockIdx.x * kGridBlock + threadIdx.x; i < n_pad; i += stride) {
+    uint32_t* seg_b = queue_b + (size_t)wave * seg_cap;
+    uint32_t cnt_b = 0, done = 0;
+    // The full evaluation of 64 queued points (about 7 % of the points end up here).  Run as soon as a batch is
+    // full: the scattered 4-byte reads and writes then hit lines this wave touched a few iterations ago (still in
+    // the L2 / Infinity Cache); at the end of the kernel they are partial-line read-modify-writes in HBM and cost
+    // as much as the whole dense pass (65 us for 7e5 points, in a launch of its own or as a tail).
+    auto full_batch = [&](uint32_t k0, uint32_t kend) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        uint32_t doubt = 0;
+        size_t j = 0;
+        if (k < kend) {
+            j = seg[k];
+            LrmVec3 p{x[j], y[j], z[j]};
+            const bool m = lrm_dist_tol(L, T, p, doubt);
+            doubt &= 0xffffu;
+            dx[j] = p.x;
+            dy[j] = p.y;
+            dz[j] = p.z;
+            if (mask) mask[j] = m;
+            if (bits) patch_bit(bits, j, m);
+        }
+        const uint64_t dm = __ballot(doubt != 0);
+        if (doubt) seg_b[cnt_b + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)j;
+        cnt_b += (uint32_t)__popcll(dm);
+    };
+    size_t i = (size_t)blockIdx.x * kGridBlock + threadIdx.x;
+    // the next iteration's coordinates are in flight while this one computes
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (i < n) { nx = x[i]; ny = y[i]; nz = z[i]; }
+    for (; i < n_pad; i += stride) {
+        LrmVec3 p{nx, ny, nz};
+        const size_t inext = i + stride;
+        if (inext < n) { nx = x[inext]; ny = y[inext]; nz = z[inext]; }
         bool m = false;
         uint32_t doubt = 0;
         if (i < n) {
-            LrmVec3 p{x[i], y[i], z[i]};
             m = lrm_dist_tolgrid(L, T, G, p, doubt);
             doubt &= 0xffffu;
             dx[i] = p.x;
@@ -259,8 +306,20 @@ __global__ __launch_bounds__(kGridBlock, LRM_TOLGRID_MIN_WAVES) void dist_tolgri
         const uint64_t dm = __ballot(doubt != 0);
         if (doubt) seg[cnt + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)i;
         cnt += (uint32_t)__popcll(dm);
+#if LRM_TOLGRID_MERGED == 2
+        if (cnt - done >= 64u) { // wave-uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the queue entries and this wave's outputs have landed
+            full_batch(done, done + 64u);
+            done += 64u;
+        }
+#endif
     }
-    if (lane == 0) counts_a[wave] = cnt;
+    if (lane == 0) counts_a[wave] = cnt; // statistic (lrm_dbg_tol_queue_counts)
+#if LRM_TOLGRID_MERGED
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (; done < cnt; done += 64u) full_batch(done, cnt);
+    if (lane == 0) counts_b[wave] = cnt_b;
+#endif
 }
 
 // one wave per segment of queue A
@@ -303,12 +362,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_mid_kernel(
             dy[i] = p.y;
             dz[i] = p.z;
             if (mask) mask[i] = m;
-            if (bits) {
-                unsigned long long* w = reinterpret_cast<unsigned long long*>(bits) + (i >> 6);
-                const unsigned long long bit = 1ull << (i & 63);
-                if (m) atomicOr(w, bit);
-                else atomicAnd(w, ~bit);
-            }
+            if (bits) patch_bit(bits, i, m);
         }
         const uint64_t dm = __ballot(doubt != 0);
         if (doubt) seg_b[cnt + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)i;
@@ -343,20 +397,29 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
 
 // ---- plane-table variant ------------------------------------------------------------------------------------
 namespace {
-// resident workgroups of dist_tolgrid_kernel for a table of `lds_bytes` (static + dynamic LDS): 160 KB per CU
-int tolgrid_blocks_per_cu(size_t lds_bytes) {
-    int b = (int)((size_t)160 * 1024 / (lds_bytes + 512)); // LDS is allocated in 512-byte granules
-    const int by_waves = 32 / (kGridBlock / 64);             // 32 waves per CU
-    if (b > by_waves) b = by_waves;
-    const int by_regs = (LRM_TOLGRID_MIN_WAVES * 4) / (kGridBlock / 64);
-    if (b > by_regs && by_regs > 0) b = by_regs;
-    return b < 1 ? 1 : b;
+// resident workgroups per CU of dist_tolgrid_kernel for a table of `dyn` bytes of dynamic LDS, as the runtime
+// sees it (LDS granularity, registers, wave slots); cached per table size
+int tolgrid_blocks_per_cu(size_t dyn) {
+    static size_t cached_dyn = ~(size_t)0;
+    static int cached = 1;
+    if (dyn != cached_dyn) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dist_tolgrid_kernel<2>, kGridBlock, dyn) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 1;
+        }
+        cached = nb;
+        cached_dyn = dyn;
+        if (getenv("LRM_TOL_DEBUG")) fprintf(stderr, "dist_tolgrid_kernel: %d workgroups of %d per CU with %zu B of dynamic LDS\n", nb, kGridBlock, dyn);
+    }
+    return cached;
 }
 } // namespace
 
 void lrm_tolgrid_plan(size_t n, size_t grid_bytes, uint32_t* blocks_out, uint32_t* seg_cap_out, size_t* workspace_words_out) {
-    const size_t lds = sizeof(TolLds) + grid_bytes - sizeof(LrmTolGridHeader);
-    size_t blocks = (size_t)256 * tolgrid_blocks_per_cu(lds);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    size_t blocks = (size_t)cus * tolgrid_blocks_per_cu(grid_bytes - sizeof(LrmTolGridHeader));
     const size_t need = (n + kGridBlock - 1) / kGridBlock;
     if (blocks > need) blocks = need ? need : 1;
     const size_t stride = blocks * kGridBlock;
@@ -380,14 +443,16 @@ hipError_t lrm_launch_dist_tolgrid(int op, const float* x, const float* y, const
     uint32_t* counts_a = queue_b + waves * seg_cap;
     uint32_t* counts_b = counts_a + waves;
     const size_t dyn = grid_bytes - sizeof(LrmTolGridHeader);
-    if (op == 2) hipLaunchKernelGGL(dist_tolgrid_kernel<2>, dim3(blocks), dim3(kGridBlock), dyn, st, x, y, z, n, TL, mask, bits, dx, dy, dz, grid_dev, (uint32_t)grid_bytes, queue_a, counts_a, seg_cap);
-    else hipLaunchKernelGGL(dist_tolgrid_kernel<1>, dim3(blocks), dim3(kGridBlock), dyn, st, x, y, z, n, TL, mask, bits, dx, dy, dz, grid_dev, (uint32_t)grid_bytes, queue_a, counts_a, seg_cap);
+    if (op == 2) hipLaunchKernelGGL(dist_tolgrid_kernel<2>, dim3(blocks), dim3(kGridBlock), dyn, st, x, y, z, n, TL, mask, bits, dx, dy, dz, grid_dev, (uint32_t)grid_bytes, queue_a, counts_a, queue_b, counts_b, seg_cap);
+    else hipLaunchKernelGGL(dist_tolgrid_kernel<1>, dim3(blocks), dim3(kGridBlock), dyn, st, x, y, z, n, TL, mask, bits, dx, dy, dz, grid_dev, (uint32_t)grid_bytes, queue_a, counts_a, queue_b, counts_b, seg_cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+#if !LRM_TOLGRID_MERGED
     if (op == 2) hipLaunchKernelGGL(tol_mid_kernel<2>, dim3((unsigned)waves), dim3(kFixBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue_a, counts_a, queue_b, counts_b, seg_cap);
     else hipLaunchKernelGGL(tol_mid_kernel<1>, dim3((unsigned)waves), dim3(kFixBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue_a, counts_a, queue_b, counts_b, seg_cap);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+#endif
     const unsigned fblocks = (unsigned)((waves + kSegPerWave - 1) / kSegPerWave);
     if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue_b, counts_b, (uint32_t)waves, seg_cap, (size_t)0);
     else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue_b, counts_b, (uint32_t)waves, seg_cap, (size_t)0);

@@ -157,6 +157,25 @@ size_t lrm_build_tol_grid(const LrmTolLeg& L, size_t max_fine, std::vector<uint8
                 coarse[(size_t)iz * LRM_TG_N + ix] = (uint16_t)code;
             }
         }
+    if (std::getenv("LRM_TOL_DEBUG")) {
+        size_t amb_fine = 0, amb_l3 = 0, l3_cells = 0;
+        for (int iz = 0; iz < LRM_TG_N; iz++)
+            for (int ix = 0; ix < LRM_TG_N; ix++) {
+                const uint16_t c = coarse[(size_t)iz * LRM_TG_N + ix];
+                if (!(c & 0x8000u) || c == LRM_TG_AMBIG16) continue;
+                const double x0 = -LRM_TG_HALF + ix * H, z0 = -LRM_TG_HALF + iz * H;
+                for (int k = 0; k < 16; k++)
+                    if (fine[(size_t)(c & 0x7fffu) * 16 + k] == LRM_TG_AMBIG8) {
+                        amb_fine++;
+                        const double fx0 = x0 + (k & 3) * h, fz0 = z0 + (k >> 2) * h;
+                        for (int q = 0; q < 16; q++) {
+                            l3_cells++;
+                            if (classify_cell(L, fx0 + ((q & 3) + 0.5) * h / 4, fz0 + ((q >> 2) + 0.5) * h / 4, 0.5 * h / 4 * 1.41421357, band, tau) == LRM_TG_AMBIG8) amb_l3++;
+                        }
+                    }
+            }
+        std::fprintf(stderr, "tol grid: %zu ambiguous fine cells (4 mm); at 1 mm %zu of their %zu sub-cells stay ambiguous\n", amb_fine, amb_l3, l3_cells);
+    }
     if (std::getenv("LRM_TOL_DEBUG"))
         std::fprintf(stderr, "tol grid: %zu refined; ambiguous cell tests by reason: rays %d validity %d centre %d clamp %d none %d tie %d cond %d\n",
                      n_fine, g_reason[0], g_reason[1], g_reason[2], g_reason[3], g_reason[4], g_reason[5], g_reason[6]);

@@ -47,6 +47,11 @@ def main():
         b.record()
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / args.reps
+        if name == "tol":
+            try:
+                out["tol_queue_counts(points, full, exact)"] = lrm_amd.dbg_tol_queue_counts()
+            except Exception as e:  # below the plane-table threshold
+                out["tol_queue_counts"] = str(e)
         out[name] = {"ms_per_call": ms, "evals_per_s": n / (ms * 1e-3), "hbm_GBs_algorithmic": 25 * n / (ms * 1e-3) / 1e9,
                      "frac_of_8TBs": 25 * n / (ms * 1e-3) / 8e12}
     lrm_amd.set_mode(lrm_amd.MODE_FAST)

@@ -171,3 +171,41 @@ def test_tol_ineligible_leg_falls_back_to_bit_exact(lrm, oracle, torch_cuda):
     want_d, _ = oracle.dist(pts, odd)
     assert np.array_equal(m.cpu().numpy(), oracle.reach(pts, odd))
     assert bits_equal(d.cpu().numpy().T, want_d).all()
+
+
+def test_tol_plane_table_variant_in_a_subprocess(lrm):
+    """LRM_TOL_PLANE_TABLE=1 (read once per process) routes clouds of >= 5e5 points through the plane-table kernel
+    (csrc/lrm_tolgrid.cpp + dist_tolgrid_kernel): same contract -- mask bit-exact, field inside the tolerance."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+import torch, lrm_amd
+from conftest import random_cloud
+from tolcheck import TOL, field_error
+from oracle.orc import Oracle
+o = Oracle()
+lrm_amd.set_mode(lrm_amd.MODE_TOL)
+pts = random_cloud(1_000_003, seed=21)
+for leg, q in ((lrm_amd.get_M2_leg(0.0), (1, 0, 0, 0)), (lrm_amd.get_moonbot_leg(1.0), (0.98, 0.0, 0.15, 0.05))):
+    x, y, z = (torch.from_numpy(np.ascontiguousarray(pts[:, k])).cuda() for k in range(3))
+    n = len(pts)
+    bits = torch.empty((n + 63) // 64, dtype=torch.int64, device='cuda')
+    m, d, bits = lrm_amd.device.reach_dist(x, y, z, leg, q, mask=torch.empty(n, dtype=torch.uint8, device='cuda'), bits=bits)
+    torch.cuda.synchronize()
+    npts, nfull, nexact = lrm_amd.dbg_tol_queue_counts()
+    assert npts == n and 0 < nfull < 0.15 * n and nexact < 0.02 * n, (npts, nfull, nexact)
+    want_m = o.reach(pts, leg, q); want_d, _ = o.dist(pts, leg, q)
+    assert np.array_equal(m.cpu().numpy(), want_m)
+    packed = np.packbits(np.pad(want_m, (0, (-n) % 64)), bitorder='little').view(np.uint64)
+    assert np.array_equal(bits.cpu().numpy().view(np.uint64), packed)
+    e = field_error(pts, d.cpu().numpy().T, want_d)
+    assert e['metric'].max() <= TOL, e['metric'].max()
+print('plane table ok')
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LRM_TOL_PLANE_TABLE="1")
+    out = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "plane table ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
