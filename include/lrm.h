@@ -9,12 +9,13 @@
  * lrm_last_error() then holds a message.  Nothing here ever computes a GPU entry point on
  * the CPU: without a usable HIP device the *_dev / host-buffer GPU calls fail with LRM_ENODEV.
  *
- * Threading: like the reference's harness (single host thread, cross_compiled.cu), the library keeps
- * process-wide state -- the arithmetic mode, the last error message, and small device workspaces
- * of the pair kernels (bounding boxes, compiled-leg slots) that are created on first use and
- * reused.  Call it from one host thread at a time; the *_dev entry points may be given any stream,
- * but the pair kernels (lrm_reach_any_dev, lrm_any_in_*_dev, lrm_positionability) share their
- * workspaces and must not run concurrently on two streams.
+ * Threading: like the reference's harness (single host thread, cross_compiled.cu) the library is meant to be called
+ * from one host thread at a time: the arithmetic mode and the caches of compiled tables are process-wide.  Device
+ * workspaces (bounding boxes and compiled-leg slots of the pair kernels, doubt queues of LRM_MODE_TOL) are kept per
+ * device -- the doubt queues per (device, stream) -- created on first use and reused; a compiled-leg slot is only
+ * rewritten after the launch that read it has completed (an event per slot), so the *_dev entry points may be
+ * queued on several streams.  The bounding boxes of the pair kernels are one buffer per device: do not run two
+ * pair launches on different clouds concurrently on one device.
  *
  * Units: millimetres and radians, float32 arithmetic (reference convention).
  * Quaternions are float[4] = {x,y,z,w} in the reference's own (inconsistent) convention:

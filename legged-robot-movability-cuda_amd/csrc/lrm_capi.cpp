@@ -477,50 +477,61 @@ int lrm_dist_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, co
 
 // ---- body x target aggregation ---------------------------------------------------------
 namespace {
-// Library-owned scratch for the bounding boxes of the pair kernels (6 floats per 1024-target tile
-// and per 64-target chunk), grown on demand: the first call for a larger cloud allocates (not capturable in a
-// graph); later calls only launch.
-float* g_boxes = nullptr;
-// Set by lrm_positionability between the kernels of one orientation: they all read the same
-// rotated cloud, so only the first one has to build its boxes.
-bool g_boxes_ready = false;
-size_t g_boxes_cap = 0; // tiles
-int g_boxes_dev = -1;
-int tile_boxes(size_t nt, float** out) {
-    const size_t ntiles = (nt + 1023) / 1024 * 17; // one box per tile + 16 chunk boxes per tile
+// Library-owned device workspaces of the pair kernels, ONE SET PER DEVICE (a process that walks over several GPUs
+// keeps them all; nothing is leaked or overwritten on a device switch):
+//   boxes  the bounding boxes of the target cloud (6 floats per 1024-target tile and per 64-target chunk), grown on
+//          demand: the first call for a larger cloud allocates (not capturable in a graph), later calls only launch;
+//   legs   kLegSlots slots of LRM_MAX_LEGS compiled legs for in-flight launches, handed out round-robin; a slot is
+//          rewritten only after the event recorded behind the launch that last read it has completed, so launches
+//          queued on several streams never see each other's legs.
+constexpr int kLegSlots = 16;
+struct DevicePool {
+    float* boxes = nullptr;
+    size_t boxes_cap = 0; // tiles
+    LrmCompiledLeg* legs = nullptr;
+    hipEvent_t slot_done[kLegSlots] = {};
+    unsigned next_slot = 0;
+};
+std::map<int, DevicePool> g_pools;
+int device_pool(DevicePool** out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
-    if (ntiles > g_boxes_cap || dev != g_boxes_dev) {
-        if (g_boxes && dev == g_boxes_dev) (void)hipFree(g_boxes);
+    *out = &g_pools[dev];
+    return LRM_OK;
+}
+int tile_boxes(size_t nt, float** out) {
+    const size_t ntiles = (nt + 1023) / 1024 * 17; // one box per tile + 16 chunk boxes per tile
+    DevicePool* P = nullptr;
+    int rc = device_pool(&P);
+    if (rc != LRM_OK) return rc;
+    if (ntiles > P->boxes_cap) {
+        if (P->boxes) (void)hipFree(P->boxes); // synchronises with launches that still read it
+        P->boxes = nullptr;
+        P->boxes_cap = 0;
         void* p = nullptr;
         const size_t cap = ntiles + ntiles / 2 + 16;
         HIP_TRY(hipMalloc(&p, cap * 6 * sizeof(float)), "hipMalloc tile boxes");
-        g_boxes = static_cast<float*>(p);
-        g_boxes_cap = cap;
-        g_boxes_dev = dev;
+        P->boxes = static_cast<float*>(p);
+        P->boxes_cap = cap;
     }
-    *out = g_boxes;
+    *out = P->boxes;
     return LRM_OK;
 }
-
-// A small per-process pool of device slots for the compiled legs of in-flight launches, so
-// that the launch path does not allocate.  16 slots x LRM_MAX_LEGS; a slot is reused after
-// 16 further launches, far beyond any stream's queue depth in this library's use.
-constexpr int kLegSlots = 16;
-LrmCompiledLeg* g_leg_pool = nullptr;
-int g_leg_pool_dev = -1;
-unsigned g_leg_slot = 0;
-int leg_slot(LrmCompiledLeg** out) {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
-    if (!g_leg_pool || g_leg_pool_dev != dev) {
-        // one pool per process and device in use; a device switch re-creates it
+// a free slot for the legs of one launch; leg_slot_used() records the event behind that launch
+int leg_slot(LrmCompiledLeg** out, hipEvent_t** done) {
+    DevicePool* P = nullptr;
+    int rc = device_pool(&P);
+    if (rc != LRM_OK) return rc;
+    if (!P->legs) {
         void* p = nullptr;
         HIP_TRY(hipMalloc(&p, sizeof(LrmCompiledLeg) * LRM_MAX_LEGS * kLegSlots), "hipMalloc leg pool");
-        g_leg_pool = static_cast<LrmCompiledLeg*>(p);
-        g_leg_pool_dev = dev;
+        P->legs = static_cast<LrmCompiledLeg*>(p);
     }
-    *out = g_leg_pool + (size_t)(g_leg_slot++ % kLegSlots) * LRM_MAX_LEGS;
+    const unsigned slot = P->next_slot++ % kLegSlots;
+    if (P->slot_done[slot]) HIP_TRY(hipEventSynchronize(P->slot_done[slot]), "hipEventSynchronize leg slot");
+    else HIP_TRY(hipEventCreateWithFlags(&P->slot_done[slot], hipEventDisableTiming), "hipEventCreate leg slot");
+    *out = P->legs + (size_t)slot * LRM_MAX_LEGS;
+    *done = &P->slot_done[slot];
     return LRM_OK;
 }
 } // namespace
@@ -528,19 +539,22 @@ int leg_slot(LrmCompiledLeg** out) {
 namespace {
 int reach_any_impl(const float* bx, const float* by, const float* bz, size_t nb, const float* tx, const float* ty,
                    const float* tz, size_t nt, const LrmLegDimensions* legs, size_t nlegs, const float* quat,
-                   const uint8_t* body_active, uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream);
+                   const uint8_t* body_active, bool boxes_ready, uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream);
+int any_in_shape_impl(int shape, const float* cx, const float* cy, const float* cz, size_t nc, const float* tx,
+                      const float* ty, const float* tz, size_t nt, float radius, float plus_z, float minus_z,
+                      bool boxes_ready, uint8_t* out, void* stream);
 }
 
 int lrm_reach_any_dev(const float* bx, const float* by, const float* bz, size_t nb, const float* tx,
                       const float* ty, const float* tz, size_t nt, const LrmLegDimensions* legs, size_t nlegs,
                       const float* quat, uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream) {
-    return reach_any_impl(bx, by, bz, nb, tx, ty, tz, nt, legs, nlegs, quat, nullptr, out_leg_body, all_legs_out, stream);
+    return reach_any_impl(bx, by, bz, nb, tx, ty, tz, nt, legs, nlegs, quat, nullptr, false, out_leg_body, all_legs_out, stream);
 }
 
 namespace {
 int reach_any_impl(const float* bx, const float* by, const float* bz, size_t nb, const float* tx, const float* ty,
                    const float* tz, size_t nt, const LrmLegDimensions* legs, size_t nlegs, const float* quat,
-                   const uint8_t* body_active, uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream) {
+                   const uint8_t* body_active, bool boxes_ready, uint8_t* out_leg_body, uint8_t* all_legs_out, void* stream) {
     if (!legs || nlegs == 0 || nlegs > LRM_MAX_LEGS) return fail(LRM_EINVAL, "nlegs must be 1..LRM_MAX_LEGS");
     if (!out_leg_body || (nb && (!bx || !by || !bz)) || (nt && (!tx || !ty || !tz)))
         return fail(LRM_EINVAL, "null argument");
@@ -548,7 +562,8 @@ int reach_any_impl(const float* bx, const float* by, const float* bz, size_t nb,
     LrmCompiledLeg host_legs[LRM_MAX_LEGS];
     for (size_t l = 0; l < nlegs; l++) lrm_compile_leg(legs[l], quat_or_default(quat), 0, &host_legs[l]);
     LrmCompiledLeg* dev_legs = nullptr;
-    int rc = leg_slot(&dev_legs);
+    hipEvent_t* slot_done = nullptr;
+    int rc = leg_slot(&dev_legs, &slot_done);
     if (rc != LRM_OK) return rc;
     HIP_TRY(hipMemcpyAsync(dev_legs, host_legs, sizeof(LrmCompiledLeg) * nlegs, hipMemcpyHostToDevice,
                            (hipStream_t)stream), "hipMemcpyAsync legs");
@@ -560,14 +575,17 @@ int reach_any_impl(const float* bx, const float* by, const float* bz, size_t nb,
         rc = tile_boxes(nt, &boxes);
         if (rc != LRM_OK) return rc;
     }
-    HIP_TRY(lrm_launch_reach_any(bx, by, bz, nb, tx, ty, tz, nt, dev_legs, (int)nlegs, boxes, g_boxes_ready, body_active,
+    HIP_TRY(lrm_launch_reach_any(bx, by, bz, nb, tx, ty, tz, nt, dev_legs, (int)nlegs, boxes, boxes_ready && boxes, body_active,
                                  out_leg_body, all_legs_out, fast, (hipStream_t)stream), "reach_any launch");
+    HIP_TRY(hipEventRecord(*slot_done, (hipStream_t)stream), "hipEventRecord leg slot"); // the slot is free again after this launch
     return LRM_OK;
 }
 } // namespace
 
-int lrm_any_in_sphere_dev(const float* cx, const float* cy, const float* cz, size_t nc, const float* tx,
-                          const float* ty, const float* tz, size_t nt, float radius, uint8_t* out, void* stream) {
+namespace {
+int any_in_shape_impl(int shape, const float* cx, const float* cy, const float* cz, size_t nc, const float* tx,
+                      const float* ty, const float* tz, size_t nt, float radius, float plus_z, float minus_z,
+                      bool boxes_ready, uint8_t* out, void* stream) {
     if (!out || (nc && (!cx || !cy || !cz)) || (nt && (!tx || !ty || !tz))) return fail(LRM_EINVAL, "null argument");
     if (nc == 0) return LRM_OK;
     float* boxes = nullptr;
@@ -575,23 +593,19 @@ int lrm_any_in_sphere_dev(const float* cx, const float* cy, const float* cz, siz
         const int rc = tile_boxes(nt, &boxes);
         if (rc != LRM_OK) return rc;
     }
-    HIP_TRY(lrm_launch_any_in_shape(0, cx, cy, cz, nc, tx, ty, tz, nt, radius, 0.f, 0.f, boxes, g_boxes_ready, out,
-                                    (hipStream_t)stream), "in_sphere launch");
+    HIP_TRY(lrm_launch_any_in_shape(shape, cx, cy, cz, nc, tx, ty, tz, nt, radius, plus_z, minus_z, boxes, boxes_ready && boxes, out,
+                                    (hipStream_t)stream), shape ? "in_cylinder launch" : "in_sphere launch");
     return LRM_OK;
+}
+} // namespace
+int lrm_any_in_sphere_dev(const float* cx, const float* cy, const float* cz, size_t nc, const float* tx,
+                          const float* ty, const float* tz, size_t nt, float radius, uint8_t* out, void* stream) {
+    return any_in_shape_impl(0, cx, cy, cz, nc, tx, ty, tz, nt, radius, 0.f, 0.f, false, out, stream);
 }
 int lrm_any_in_cylinder_dev(const float* cx, const float* cy, const float* cz, size_t nc, const float* tx,
                             const float* ty, const float* tz, size_t nt, float radius, float plus_z, float minus_z,
                             uint8_t* out, void* stream) {
-    if (!out || (nc && (!cx || !cy || !cz)) || (nt && (!tx || !ty || !tz))) return fail(LRM_EINVAL, "null argument");
-    if (nc == 0) return LRM_OK;
-    float* boxes = nullptr;
-    if (nt >= 4096) {
-        const int rc = tile_boxes(nt, &boxes);
-        if (rc != LRM_OK) return rc;
-    }
-    HIP_TRY(lrm_launch_any_in_shape(1, cx, cy, cz, nc, tx, ty, tz, nt, radius, plus_z, minus_z, boxes, g_boxes_ready, out,
-                                    (hipStream_t)stream), "in_cylinder launch");
-    return LRM_OK;
+    return any_in_shape_impl(1, cx, cy, cz, nc, tx, ty, tz, nt, radius, plus_z, minus_z, false, out, stream);
 }
 
 // Morton order of a host cloud (see morton_order above): order_out[k] = index of the k-th point.
@@ -880,9 +894,7 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
         for (size_t qi = 0; qi < nquat; qi++) lrm_compile_leg(dummy, quats + 4 * qi, 0, &rots[qi]); // only fwd_rot is used
         if (nquat) HIP_TRY(hipMemcpy(d_rot.p, rots.data(), sizeof(LrmCompiledLeg) * nquat, hipMemcpyHostToDevice), "hipMemcpy rotations");
     }
-    struct BoxesReuse { // the kernels of one orientation share the rotated cloud's boxes
-        ~BoxesReuse() { g_boxes_ready = false; }
-    } boxes_reuse_guard;
+    bool boxes_ready = false; // the kernels of one orientation share the rotated cloud's boxes: only the first builds them
     HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
     for (size_t qi = 0; qi < nquat; qi++) {
         const float* q = quats + 4 * qi;
@@ -891,7 +903,7 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
         const LrmCompiledLeg* rot_dev = d_rot.as<LrmCompiledLeg>() + qi;
         HIP_TRY(lrm_launch_rotate_soa(B0, B0 + pb, B0 + 2 * pb, nb, rot_dev, B, B + pb, B + 2 * pb, nullptr), "rotate bodies");
         if (mt) HIP_TRY(lrm_launch_rotate_soa(T0, T0 + pt, T0 + 2 * pt, mt, rot_dev, T, T + pt, T + 2 * pt, nullptr), "rotate targets");
-        g_boxes_ready = false; // new rotated cloud
+        boxes_ready = false; // new rotated cloud
         int rc = LRM_OK;
         if (reference_culls) {
             // eliminateFarAndColliding, several_leg.cu:504-525, with the rotated leg 0
@@ -903,16 +915,16 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
                                    d.femur_length * sinf(half_pi < d.max_angle_femur ? half_pi : d.max_angle_femur);
             const float plus_z_in = s_pitch * d.coxa_length + plus_abs;
             const float minus_z_in = s_pitch * d.coxa_length - d.femur_length - d.tibia_length;
-            rc = lrm_any_in_cylinder_dev(B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, radius_in, plus_z_in, minus_z_in,
-                                         d_m1.as<uint8_t>(), nullptr);
-            g_boxes_ready = mt >= 4096;
+            rc = any_in_shape_impl(1, B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, radius_in, plus_z_in, minus_z_in,
+                                   boxes_ready, d_m1.as<uint8_t>(), nullptr);
+            boxes_ready = mt >= 4096;
             if (rc == LRM_OK)
-                rc = lrm_any_in_cylinder_dev(B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, d.body, 250.f, -110.f,
-                                             d_m2.as<uint8_t>(), nullptr);
+                rc = any_in_shape_impl(1, B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, d.body, 250.f, -110.f,
+                                       boxes_ready, d_m2.as<uint8_t>(), nullptr);
             if (rc != LRM_OK) return rc;
         }
         rc = reach_any_impl(B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, rl, nlegs, q, d_active.as<uint8_t>(),
-                            d_leg_body.as<uint8_t>(), d_all.as<uint8_t>(), nullptr);
+                            boxes_ready, d_leg_body.as<uint8_t>(), d_all.as<uint8_t>(), nullptr);
         if (rc != LRM_OK) return rc;
         HIP_TRY(lrm_launch_sweep_update(d_all.as<uint8_t>(), d_m1.as<uint8_t>(), d_m2.as<uint8_t>(), reference_culls ? 1 : 0, nb,
                                         d_active.as<uint8_t>(), d_accepted.as<uint8_t>(), nullptr), "sweep update");

@@ -251,7 +251,24 @@ __global__ __launch_bounds__(kBlock, kFast ? LRM_DIST_MIN_WAVES : LRM_DIST_STRIC
         bool m = false;
         if (i < n) {
             LrmVec3 p{x[i], y[i], z[i]};
-            const bool v = eval_reach_dist<kOp, kFast>(L, &s_tab, p, m);
+            bool v;
+            if (kOp == 2 && kFast) {
+                // as lrm_reach_dist_global_filtered, but the (rare) strict re-evaluation of the mask re-loads the
+                // point instead of keeping it live across the whole distance evaluation (3 VGPRs: the difference
+                // between 72 registers with one spilled and 72 without)
+                uint32_t stat = 0;
+                LrmDistByproduct by;
+                v = lrm_dist_global_fast(L, LrmDistTables{s_tab.lists, s_tab.dist, s_tab.corners}, p, stat, &by);
+                bool doubt;
+                m = lrm_reach_from_dist(L, by, doubt);
+                if (doubt) {
+                    size_t ii = i;
+                    asm volatile("" : "+v"(ii)); // opaque: a real re-load, or the compiler keeps the point (and |x|, ...) live for this path
+                    m = lrm_reach_global(L, s_tab.lists, LrmVec3{x[ii], y[ii], z[ii]});
+                }
+            } else {
+                v = eval_reach_dist<kOp, kFast>(L, &s_tab, p, m);
+            }
             dx[i] = p.x;
             dy[i] = p.y;
             dz[i] = p.z;

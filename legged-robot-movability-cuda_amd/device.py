@@ -14,17 +14,37 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
-def _stream():
-    return _torch().cuda.current_stream().cuda_stream
+def _stream(ref=None):
+    """torch's current stream ON THE DEVICE OF THE INPUTS (not on whatever device is current)"""
+    torch = _torch()
+    return torch.cuda.current_stream(ref.device if ref is not None else None).cuda_stream
 
 
 def _check_f32(*ts):
     torch = _torch()
     n = ts[0].numel()
+    dev = ts[0].device
     for t in ts:
-        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
-            raise ValueError("expected contiguous float32 CUDA tensors of equal length")
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n and t.device == dev):
+            raise ValueError("expected contiguous float32 CUDA tensors of equal length on one device")
     return n
+
+
+def _check_out(t, ref, dtype, numel, what):
+    """Caller-supplied outputs go to the kernels as raw pointers: a short, strided, mistyped or other-device tensor
+    would be an out-of-bounds device write."""
+    if t is None:
+        return
+    if not (t.is_cuda and t.device == ref.device and t.dtype == dtype and t.is_contiguous() and t.numel() >= numel):
+        raise ValueError(f"{what}: expected a contiguous {dtype} tensor of >= {numel} elements on {ref.device}")
+
+
+def _check_field(out, ref, n):
+    """(3, n) distance field whose three rows are each contiguous (row stride may exceed n: a view of a wider buffer)"""
+    torch = _torch()
+    if not (out.is_cuda and out.device == ref.device and out.dtype == torch.float32 and out.dim() == 2 and out.shape[0] == 3
+            and out.shape[1] >= n and (out.shape[1] <= 1 or out.stride(1) == 1)):
+        raise ValueError(f"distance field: expected a float32 (3, >= {n}) tensor with contiguous rows on {ref.device}")
 
 
 def _leg(leg):
@@ -44,14 +64,17 @@ def reach(x, y, z, leg, quat=None, out=None, bits=None, want_bits=False):
         out = torch.empty(n, dtype=torch.uint8, device=x.device)
     if want_bits and bits is None:
         bits = torch.empty((n + 63) // 64, dtype=torch.int64, device=x.device)
+    _check_out(out, x, torch.uint8, n, "mask")
+    _check_out(bits, x, torch.int64, (n + 63) // 64, "bit words")
     leg = _leg(leg)
     q = _q(quat)
     L = _capi.load()
-    if bits is not None:
-        _capi.check(L.lrm_reach_bits_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q), _dp(out),
-                                         _dp(bits), _stream()))
-        return out, bits
-    _capi.check(L.lrm_reach_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q), _dp(out), _stream()))
+    with torch.cuda.device(x.device):
+        if bits is not None:
+            _capi.check(L.lrm_reach_bits_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q), _dp(out),
+                                             _dp(bits), _stream(x)))
+            return out, bits
+        _capi.check(L.lrm_reach_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q), _dp(out), _stream(x)))
     return out
 
 
@@ -62,10 +85,13 @@ def dist(x, y, z, leg, quat=None, out=None, valid=None, want_valid=True):
         out = torch.empty((3, n), dtype=torch.float32, device=x.device)
     if valid is None and want_valid:
         valid = torch.empty(n, dtype=torch.uint8, device=x.device)
+    _check_field(out, x, n)
+    _check_out(valid, x, torch.uint8, n, "validity bytes")
     leg = _leg(leg)
     q = _q(quat)
-    _capi.check(_capi.load().lrm_dist_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q), _dp(out[0]),
-                                          _dp(out[1]), _dp(out[2]), _dp(valid), _stream()))
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.load().lrm_dist_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q), _dp(out[0]),
+                                              _dp(out[1]), _dp(out[2]), _dp(valid), _stream(x)))
     return out, valid
 
 
@@ -77,11 +103,15 @@ def reach_dist(x, y, z, leg, quat=None, mask=None, out=None, bits=None):
         out = torch.empty((3, n), dtype=torch.float32, device=x.device)
     if mask is None and bits is None:
         mask = torch.empty(n, dtype=torch.uint8, device=x.device)
+    _check_field(out, x, n)
+    _check_out(mask, x, torch.uint8, n, "mask")
+    _check_out(bits, x, torch.int64, (n + 63) // 64, "bit words")
     leg = _leg(leg)
     q = _q(quat)
-    _capi.check(_capi.load().lrm_reach_dist_bits_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q),
-                                                     _dp(mask), _dp(bits), _dp(out[0]), _dp(out[1]), _dp(out[2]),
-                                                     _stream()))
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.load().lrm_reach_dist_bits_dev(_dp(x), _dp(y), _dp(z), n, _capi._ptr(leg), _capi._ptr(q),
+                                                         _dp(mask), _dp(bits), _dp(out[0]), _dp(out[1]), _dp(out[2]),
+                                                         _stream(x)))
     if bits is not None:
         return mask, out, bits
     return mask, out
@@ -99,9 +129,14 @@ def reach_any(bx, by, bz, tx, ty, tz, legs, quat=None, out=None, all_legs=None):
     if all_legs is None:
         all_legs = torch.empty(nb, dtype=torch.uint8, device=bx.device)
     q = _q(quat)
-    _capi.check(_capi.load().lrm_reach_any_dev(_dp(bx), _dp(by), _dp(bz), nb, _dp(tx), _dp(ty), _dp(tz), nt,
-                                               _capi._ptr(legs), len(legs), _capi._ptr(q), _dp(out),
-                                               _dp(all_legs), _stream()))
+    _check_out(out, bx, torch.uint8, len(legs) * nb, "per-leg results")
+    _check_out(all_legs, bx, torch.uint8, nb, "per-body results")
+    if nt and tx.device != bx.device:
+        raise ValueError("bodies and targets must live on one device")
+    with torch.cuda.device(bx.device):
+        _capi.check(_capi.load().lrm_reach_any_dev(_dp(bx), _dp(by), _dp(bz), nb, _dp(tx), _dp(ty), _dp(tz), nt,
+                                                   _capi._ptr(legs), len(legs), _capi._ptr(q), _dp(out),
+                                                   _dp(all_legs), _stream(bx)))
     return out, all_legs
 
 
@@ -111,8 +146,10 @@ def any_in_sphere(cx, cy, cz, tx, ty, tz, radius, out=None):
     nt = _check_f32(tx, ty, tz)
     if out is None:
         out = torch.empty(nc, dtype=torch.uint8, device=cx.device)
-    _capi.check(_capi.load().lrm_any_in_sphere_dev(_dp(cx), _dp(cy), _dp(cz), nc, _dp(tx), _dp(ty), _dp(tz), nt,
-                                                   radius, _dp(out), _stream()))
+    _check_out(out, cx, torch.uint8, nc, "results")
+    with torch.cuda.device(cx.device):
+        _capi.check(_capi.load().lrm_any_in_sphere_dev(_dp(cx), _dp(cy), _dp(cz), nc, _dp(tx), _dp(ty), _dp(tz), nt,
+                                                       radius, _dp(out), _stream(cx)))
     return out
 
 
@@ -122,6 +159,8 @@ def any_in_cylinder(cx, cy, cz, tx, ty, tz, radius, plus_z, minus_z, out=None):
     nt = _check_f32(tx, ty, tz)
     if out is None:
         out = torch.empty(nc, dtype=torch.uint8, device=cx.device)
-    _capi.check(_capi.load().lrm_any_in_cylinder_dev(_dp(cx), _dp(cy), _dp(cz), nc, _dp(tx), _dp(ty), _dp(tz), nt,
-                                                     radius, plus_z, minus_z, _dp(out), _stream()))
+    _check_out(out, cx, torch.uint8, nc, "results")
+    with torch.cuda.device(cx.device):
+        _capi.check(_capi.load().lrm_any_in_cylinder_dev(_dp(cx), _dp(cy), _dp(cz), nc, _dp(tx), _dp(ty), _dp(tz), nt,
+                                                         radius, plus_z, minus_z, _dp(out), _stream(cx)))
     return out

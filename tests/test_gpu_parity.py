@@ -77,10 +77,14 @@ def test_ragged_sizes(lrm, oracle, torch_cuda, n):
         m, _ = lrm.apply_reach(pts, leg, q)
         assert m.shape == (0,)
         return
-    x, y, z = soa(torch_cuda, pts)
+    # three separately allocated (16-byte aligned) component arrays: for n % 4 != 0 the rows of ONE (3, n)
+    # tensor are misaligned and would always take the scalar kernel -- this way the vector kernel's n % 4 tail
+    # and partial-word code run too
+    x, y, z = (torch_cuda.from_numpy(np.ascontiguousarray(pts[:, k])).cuda() for k in range(3))
+    assert all(t.data_ptr() % 16 == 0 for t in (x, y, z))
     # guard bytes after every output: kernels must not write past n
     mask = torch_cuda.full((n + 64,), 7, dtype=torch_cuda.uint8, device="cuda")
-    out = torch_cuda.full((3, n + 16), -777.0, dtype=torch_cuda.float32, device="cuda")
+    out = torch_cuda.full((3, ((n + 16 + 3) // 4) * 4), -777.0, dtype=torch_cuda.float32, device="cuda")  # rows stay 16-byte aligned
     bits = torch_cuda.full(((n + 63) // 64 + 2,), -1, dtype=torch_cuda.int64, device="cuda")
     lrm.device.reach(x, y, z, leg, q, out=mask[:n], bits=bits[:(n + 63) // 64])
     ox = [out[i, :n] for i in range(3)]
@@ -303,3 +307,28 @@ def test_config4_cloud_1e8_points_on_one_gpu(lrm, oracle, torch_cuda, mode):
     m2 = lrm.device.reach(dev[0][w0:w0 + wn], dev[1][w0:w0 + wn], dev[2][w0:w0 + wn], leg)
     torch_cuda.cuda.synchronize()
     assert np.array_equal(m2.cpu().numpy(), mask[w0:w0 + wn])
+
+
+def test_device_api_rejects_bad_output_tensors(lrm, torch_cuda):
+    """Outputs travel as raw pointers: short, mistyped, strided or host tensors must be refused, not written through."""
+    pts = random_cloud(1000, seed=1)
+    x, y, z = soa(torch_cuda, pts)
+    leg = lrm.get_M2_leg(0.0)
+    t = torch_cuda
+    with pytest.raises(ValueError):
+        lrm.device.reach(x, y, z, leg, out=t.empty(999, dtype=t.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        lrm.device.reach(x, y, z, leg, out=t.empty(1000, dtype=t.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        lrm.device.reach(x, y, z, leg, bits=t.empty(15, dtype=t.int64, device="cuda"))
+    with pytest.raises(ValueError):
+        lrm.device.dist(x, y, z, leg, out=t.empty((1000, 3), dtype=t.float32, device="cuda").T)  # rows not contiguous
+    with pytest.raises(ValueError):
+        lrm.device.dist(x, y, z, leg, out=t.empty((3, 999), dtype=t.float32, device="cuda"))
+    with pytest.raises(ValueError):
+        lrm.device.reach_dist(x, y, z, leg, mask=t.empty(1000, dtype=t.uint8))  # host tensor
+    # a view of a wider buffer is fine (contiguous rows)
+    wide = t.empty((3, 1024), dtype=t.float32, device="cuda")
+    d, v = lrm.device.dist(x, y, z, leg, out=wide[:, :1000])
+    t.cuda.synchronize()
+    assert d.shape == (3, 1000)
