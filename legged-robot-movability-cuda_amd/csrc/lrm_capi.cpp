@@ -276,6 +276,13 @@ std::vector<size_t> morton_order(const float* aos, const std::vector<size_t>& id
 }
 } // namespace
 
+// Morton order for other translation units (lrm_octree.hip)
+void lrm_host_morton_order(const float* xyz_aos, size_t n, std::vector<size_t>* order) {
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = i;
+    *order = morton_order(xyz_aos, idx);
+}
+
 extern "C" {
 
 const char* lrm_version(void) { return "lrm-mi355x 0.1 (gfx950)"; }

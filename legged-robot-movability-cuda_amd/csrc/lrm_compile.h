@@ -28,3 +28,6 @@ void lrm_compile_tol(const LrmCompiledLeg& L, LrmTolLeg* out);
 // The plane table of the tolerance mode (lrm_types.h: LrmTolGridHeader | uint16 coarse[LRM_TG_N^2] | uint8 fine[16 n_fine])
 // for an eligible leg; at most max_fine coarse cells are refined.  Returns n_fine.
 size_t lrm_build_tol_grid(const LrmTolLeg& L, size_t max_fine, std::vector<uint8_t>* out);
+
+// order[k] = index of the k-th point of the AoS cloud along a Morton (Z) curve over its bounding box (lrm_capi.cpp)
+void lrm_host_morton_order(const float* xyz_aos, size_t n, std::vector<size_t>* order);

@@ -22,8 +22,10 @@
 // committed.  No reference run exists for this path: parity is pinned by composition of the pinned
 // distance_global only, against tests/octree_oracle.py.)
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -89,6 +91,129 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_kernel(
     // wave OR, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) mine |= __shfl_xor(mine, off);
     if ((threadIdx.x & 63) == 0 && mine) atomicOr(&flags[blockIdx.y], mine);
+}
+
+// ---- scale: footholds binned by bounding boxes --------------------------------------------------------
+// oct_validity_kernel above walks EVERY foothold for every child: fine for the few, huge boxes of the first levels
+// (its grid spreads the footholds of one child over the chip), hopeless deeper down, where a level has thousands
+// of small children that each see a handful of footholds.  From kOctChunkedFrom children on, a level runs
+// oct_validity_chunked_kernel instead: the footholds are in Morton order (sorted once per call), two levels of
+// axis-aligned boxes cover them in memory order (one per 1024-foothold tile, one per 64-foothold chunk, built once
+// per call by oct_boxes_kernel), and a workgroup = one child tests tile boxes, then the chunk boxes of the
+// surviving tiles, against the child's elongated box (several_leg_octree.cu:76-82) and evaluates only the
+// footholds of surviving chunks.  A child whose three flags are all set stops at once (they are ORs).
+constexpr int kOctChunkedFrom = 65;
+constexpr int kOctMaxChunks = 4096; // surviving chunks per round of 256 tiles
+
+__global__ __launch_bounds__(kOctBlock) void oct_boxes_kernel(const float* __restrict__ fx, const float* __restrict__ fy,
+                                                             const float* __restrict__ fz, size_t nf, size_t ntiles,
+                                                             float* __restrict__ boxes) {
+    __shared__ float s_red[6][16];
+    const size_t t0 = (size_t)blockIdx.x * 1024;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int sub = wave; sub < 16; sub += kOctBlock / 64) {
+        const size_t i = t0 + (size_t)sub * 64 + lane;
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        if (i < nf) {
+            lo[0] = hi[0] = fx[i];
+            lo[1] = hi[1] = fy[i];
+            lo[2] = hi[2] = fz[i];
+        }
+        for (int a = 0; a < 3; a++)
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+            }
+        if (lane == 0) {
+            const size_t c = (size_t)blockIdx.x * 16 + sub;
+            for (int a = 0; a < 3; a++) {
+                s_red[a][sub] = lo[a];
+                s_red[3 + a][sub] = hi[a];
+                boxes[(ntiles + c) * 6 + a] = lo[a]; // an empty chunk keeps (+big, -big): it meets nothing
+                boxes[(ntiles + c) * 6 + 3 + a] = hi[a];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s_red[threadIdx.x][0];
+        for (int w = 1; w < 16; w++) v = (threadIdx.x < 3) ? fminf(v, s_red[threadIdx.x][w]) : fmaxf(v, s_red[threadIdx.x][w]);
+        boxes[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// does the box [lo, hi] hold a point p with -H < p - c <= H on every axis (in_box's asymmetric test)?  Conservative.
+__device__ __forceinline__ bool box_meets(const float* bb, const float* c, const float* H) {
+    return bb[0] <= c[0] + H[0] && bb[3] >= c[0] - H[0] && bb[1] <= c[1] + H[1] && bb[4] >= c[1] - H[1] &&
+           bb[2] <= c[2] + H[2] && bb[5] >= c[2] - H[2];
+}
+
+template <bool kFast>
+__global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
+    const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
+    const float* __restrict__ fy, const float* __restrict__ fz, size_t nf, const float* __restrict__ boxes, size_t ntiles,
+    const LrmCompiledLeg* __restrict__ legs, int leg_count, int legs_for_stab, float reach_len, float convex_r2,
+    uint32_t* __restrict__ flags) {
+    __shared__ uint32_t s_flags, s_ntiles, s_nchunks;
+    __shared__ uint32_t s_tiles[kOctBlock];
+    __shared__ uint32_t s_chunks[kOctMaxChunks];
+    for (size_t child = blockIdx.x; child < (size_t)n_children; child += gridDim.x) {
+        const OctChild ch = children[child];
+        if (ch.skip) continue; // block-uniform
+        const float H[3] = {fabsf(ch.ph[0] + reach_len), fabsf(ch.ph[1] + reach_len), fabsf(ch.ph[2] + reach_len)};
+        const float h2 = ch.h[0] * ch.h[0] + ch.h[1] * ch.h[1] + ch.h[2] * ch.h[2];
+        if (threadIdx.x == 0) s_flags = 0;
+        __syncthreads();
+        for (size_t tile0 = 0; tile0 < ntiles; tile0 += kOctBlock) {
+            if (threadIdx.x == 0) { s_ntiles = 0; s_nchunks = 0; }
+            __syncthreads();
+            if (s_flags == 7u) break; // nothing left to learn (block-uniform: read after the barrier)
+            const size_t t = tile0 + threadIdx.x;
+            if (t < ntiles && box_meets(boxes + t * 6, ch.c, H)) s_tiles[atomicAdd(&s_ntiles, 1u)] = (uint32_t)t;
+            __syncthreads();
+            const uint32_t nt = s_ntiles;
+            for (uint32_t k = threadIdx.x; k < nt * 16u; k += kOctBlock) {
+                const size_t c = (size_t)s_tiles[k >> 4] * 16 + (k & 15u);
+                if (box_meets(boxes + (ntiles + c) * 6, ch.c, H)) s_chunks[atomicAdd(&s_nchunks, 1u)] = (uint32_t)c;
+            }
+            __syncthreads();
+            const uint32_t nchunks = s_nchunks;
+            for (uint32_t k = threadIdx.x >> 6; k < nchunks; k += kOctBlock / 64) { // a wave per surviving chunk
+                if (*reinterpret_cast<volatile uint32_t*>(&s_flags) == 7u) break;
+                const size_t f = (size_t)s_chunks[k] * 64 + (threadIdx.x & 63);
+                uint32_t mine = 0;
+                if (f < nf) {
+                    const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
+                    if (in_box(vect, ch.ph[0] + reach_len, ch.ph[1] + reach_len, ch.ph[2] + reach_len)) {
+                        for (int a = 0; a < ch.n_angles; a++) {
+                            int reach_count = 0, cross_count = 0;
+                            for (int l = 0; l < leg_count; l++) {
+                                const LrmCompiledLeg& L = legs[a * leg_count + l];
+                                LrmVec3 v = vect;
+                                bool sub;
+                                if (kFast) sub = lrm_dist_global_filtered(L, LrmDistTables{&L.lists[0][0], &L.dist_tab[0][0], &L.corner_tab[0]}, v);
+                                else sub = lrm_dist_global(L, &L.lists[0][0], v);
+                                bool cross;
+                                if (h2 > convex_r2) cross = in_box(v, ch.h[0], ch.h[1], ch.h[2]);
+                                else cross = (v.x * v.x + v.y * v.y + v.z * v.z) < h2 + ch.margin;
+                                cross_count += cross;
+                                reach_count += sub;
+                            }
+                            const bool edge = cross_count > leg_count - legs_for_stab;
+                            const bool reach = ch.parent_valid || (reach_count >= legs_for_stab);
+                            mine |= (reach ? 1u : 0u) | ((reach && !edge) ? 2u : 0u) | (edge ? 4u : 0u);
+                        }
+                    }
+                }
+                for (int off = 32; off > 0; off >>= 1) mine |= __shfl_xor(mine, off);
+                if ((threadIdx.x & 63) == 0 && mine) atomicOr(&s_flags, mine);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) flags[child] = s_flags;
+        __syncthreads();
+    }
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -210,7 +335,7 @@ int lrm_apply_oct(const float* footholds, size_t nf, const LrmLegDimensions* dim
             return (e_ == hipErrorOutOfMemory) ? LRM_ENOMEM : LRM_ENODEV;      \
         }                                                                      \
     } while (0)
-    float *d_f = nullptr;
+    float *d_f = nullptr, *d_boxes = nullptr;
     LrmCompiledLeg* d_legs = nullptr;
     OctChild* d_children = nullptr;
     uint32_t* d_flags = nullptr;
@@ -218,6 +343,7 @@ int lrm_apply_oct(const float* footholds, size_t nf, const LrmLegDimensions* dim
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     auto cleanup = [&]() {
         if (d_f) (void)hipFree(d_f);
+        if (d_boxes) (void)hipFree(d_boxes);
         if (d_legs) (void)hipFree(d_legs);
         if (d_children) (void)hipFree(d_children);
         if (d_flags) (void)hipFree(d_flags);
@@ -225,15 +351,27 @@ int lrm_apply_oct(const float* footholds, size_t nf, const LrmLegDimensions* dim
         if (ev_b) (void)hipEventDestroy(ev_b);
     };
 
-    // footholds as SoA on the device
+    // footholds as SoA on the device, in Morton order (the flags are ORs over footholds: the order changes nothing,
+    // but consecutive footholds then fill compact boxes for oct_validity_chunked_kernel)
     std::vector<float> soa(3 * (nf ? nf : 1));
-    for (size_t i = 0; i < nf; i++) {
-        soa[i] = footholds[3 * i];
-        soa[nf + i] = footholds[3 * i + 1];
-        soa[2 * nf + i] = footholds[3 * i + 2];
+    {
+        std::vector<size_t> order;
+        lrm_host_morton_order(footholds, nf, &order);
+        for (size_t k = 0; k < nf; k++) {
+            const size_t i = order[k];
+            soa[k] = footholds[3 * i];
+            soa[nf + k] = footholds[3 * i + 1];
+            soa[2 * nf + k] = footholds[3 * i + 2];
+        }
     }
     OCT_TRY(hipMalloc(&d_f, soa.size() * sizeof(float)), "hipMalloc gpu_in.elements");
     OCT_TRY(hipMemcpy(d_f, soa.data(), soa.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy gpu_in.elements");
+    const size_t ntiles = (nf + 1023) / 1024;
+    if (nf) {
+        OCT_TRY(hipMalloc(&d_boxes, ntiles * 17 * 6 * sizeof(float)), "hipMalloc foothold boxes");
+        hipLaunchKernelGGL(oct_boxes_kernel, dim3((unsigned)ntiles), dim3(kOctBlock), 0, nullptr, d_f, d_f + nf, d_f + 2 * nf, nf, ntiles, d_boxes);
+        OCT_TRY(hipGetLastError(), "Kernel launch");
+    }
 
     // compiled legs for every (orientation sample, mounted leg)
     const int n_angles_max = st.angle_sample[0] * st.angle_sample[1] * st.angle_sample[2];
@@ -249,7 +387,7 @@ int lrm_apply_oct(const float* footholds, size_t nf, const LrmLegDimensions* dim
             all_fast = all_fast && legs[(size_t)a * st.leg_count + l].fast_ok;
         }
     }
-    const bool fast = all_fast && lrm_get_mode() == LRM_MODE_FAST;
+    const bool fast = all_fast && lrm_get_mode() != LRM_MODE_STRICT;
     OCT_TRY(hipMalloc(&d_legs, legs.size() * sizeof(LrmCompiledLeg)), "hipMalloc legs");
     OCT_TRY(hipMemcpy(d_legs, legs.data(), legs.size() * sizeof(LrmCompiledLeg), hipMemcpyHostToDevice), "hipMemcpy legs");
     OCT_TRY(hipEventCreate(&ev_a), "hipEventCreate");
@@ -316,18 +454,31 @@ int lrm_apply_oct(const float* footholds, size_t nf, const LrmLegDimensions* dim
         OCT_TRY(hipMemset(d_flags, 0, nc * sizeof(uint32_t)), "hipMemset flags");
         std::vector<uint32_t> flags(nc, 0);
         if (nf) {
-            size_t gx = (nf + kOctBlock - 1) / kOctBlock;
-            if (gx > 1024) gx = 1024;
-            const dim3 grid((unsigned)gx, (unsigned)nc);
             OCT_TRY(hipEventRecord(ev_a, nullptr), "hipEventRecord");
-            if (fast)
-                hipLaunchKernelGGL(oct_validity_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                   d_f + 2 * nf, nf, d_legs, st.leg_count, st.leg_number_for_stab, reach_len,
-                                   st.convex_radius * st.convex_radius, d_flags);
-            else
-                hipLaunchKernelGGL(oct_validity_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                   d_f + 2 * nf, nf, d_legs, st.leg_count, st.leg_number_for_stab, reach_len,
-                                   st.convex_radius * st.convex_radius, d_flags);
+            const float cr2 = st.convex_radius * st.convex_radius;
+            // LRM_OCT_BRUTE=1 (tests): every level with the every-foothold kernel, for comparison
+            const bool brute = getenv("LRM_OCT_BRUTE") && getenv("LRM_OCT_BRUTE")[0] == '1' && nc <= 65535;
+            if (nc >= (size_t)kOctChunkedFrom && !brute) {
+                // many small children: one workgroup per child, only the footholds of nearby chunks
+                const dim3 grid((unsigned)std::min<size_t>(nc, (size_t)256 * 64));
+                if (fast)
+                    hipLaunchKernelGGL(oct_validity_chunked_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+                else
+                    hipLaunchKernelGGL(oct_validity_chunked_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+            } else {
+                // few, huge children (the first levels): every foothold, spread over the chip; grid.y = children < 65
+                size_t gx = (nf + kOctBlock - 1) / kOctBlock;
+                if (gx > 1024) gx = 1024;
+                const dim3 grid((unsigned)gx, (unsigned)nc);
+                if (fast)
+                    hipLaunchKernelGGL(oct_validity_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
+                                       d_f + 2 * nf, nf, d_legs, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+                else
+                    hipLaunchKernelGGL(oct_validity_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
+                                       d_f + 2 * nf, nf, d_legs, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+            }
             OCT_TRY(hipGetLastError(), "Kernel launch");
             OCT_TRY(hipEventRecord(ev_b, nullptr), "hipEventRecord");
             OCT_TRY(hipMemcpy(flags.data(), d_flags, nc * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy flags");

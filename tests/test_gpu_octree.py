@@ -85,3 +85,40 @@ def test_apply_oct_defaults_and_capacity(lrm, oracle):
     # no footholds: nothing is valid
     empty, _ = lrm.apply_oct(np.zeros((0, 3), np.float32), dim, st)
     assert len(empty) == 0
+
+
+def test_apply_oct_at_scale_chunked_equals_every_foothold_kernel(lrm, oracle, mode):
+    """1e6 footholds (a 4 m x 4 m relief), depth 5: levels with >= 65 children run the chunk-culled kernel (one
+    workgroup per child, only the footholds of nearby 64-foothold chunks).  Its leaves must equal, bit for bit, the
+    every-foothold kernel's (LRM_OCT_BRUTE=1) and must not depend on the order of the footholds; a sample of valid
+    leaves is re-derived with the oracle: some foothold within reach is reachable by >= stab legs from the centre."""
+    import os
+    if mode == "strict":
+        pytest.skip("one arithmetic mode is enough at this size")
+    rng = np.random.default_rng(77)
+    n = 1_000_000
+    xy = rng.uniform(-2000, 2000, (n, 2))
+    z = 60 * np.sin(xy[:, 0] / 300) * np.cos(xy[:, 1] / 250) + rng.normal(0, 3, n) - 150
+    f = np.column_stack([xy, z]).astype(np.float32)
+    dim = lrm.get_M2_leg(0.0)
+    st = settings(lrm, 2000.0, 5, stab=3)
+    got, ms = lrm.apply_oct(f, dim, st)
+    os.environ["LRM_OCT_BRUTE"] = "1"
+    try:
+        brute, ms_brute = lrm.apply_oct(f, dim, st)
+    finally:
+        del os.environ["LRM_OCT_BRUTE"]
+    assert len(got) > 50 and np.array_equal(got.view(np.uint32), brute.view(np.uint32))
+    shuffled, _ = lrm.apply_oct(f[rng.permutation(n)], dim, st)
+    assert np.array_equal(got.view(np.uint32), shuffled.view(np.uint32))
+    print(f"apply_oct, 1e6 footholds, depth 5: {len(got)} valid leaves; chunk-culled {ms:.2f} ms of kernels, every-foothold {ms_brute:.2f} ms")
+    legs = []
+    for l in range(st.leg_count):
+        leg = np.array(dim, np.float32).copy()
+        leg[0] = np.float32(st.leg_mount[l])
+        legs.append(leg)
+    reach_len = dim[1] + dim[3] + dim[5] + dim[4]
+    for c in got[rng.choice(len(got), 6, replace=False)]:
+        near = f[np.abs(f - c).max(axis=1) < reach_len + 130.0] - c
+        count = sum(oracle.dist(near.astype(np.float32), leg)[1].astype(int) for leg in legs)
+        assert (count >= st.leg_number_for_stab).any(), "a valid leaf must have a foothold that enough legs reach"
