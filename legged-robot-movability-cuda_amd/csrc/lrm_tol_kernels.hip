@@ -282,7 +282,9 @@ __global__ __launch_bounds__(kGridBlock, LRM_TOLGRID_MIN_WAVES) void dist_tolgri
         cnt_b += (uint32_t)__popcll(dm);
     };
     size_t i = (size_t)blockIdx.x * kGridBlock + threadIdx.x;
-    // the next iteration's coordinates are in flight while this one computes
+    // The next iteration's coordinates are in flight while this one computes.  (Two points per lane and iteration,
+    // to overlap the dependent LDS lookups of two chains, was slower: 87 us against 79 -- the kernel is bound by
+    // VALU issue, 70 % of its instructions being half-rate selects, compares and 64-bit address arithmetic.)
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (i < n) { nx = x[i]; ny = y[i]; nz = z[i]; }
     for (; i < n_pad; i += stride) {
@@ -292,7 +294,12 @@ __global__ __launch_bounds__(kGridBlock, LRM_TOLGRID_MIN_WAVES) void dist_tolgri
         bool m = false;
         uint32_t doubt = 0;
         if (i < n) {
+#if defined(LRM_TOLGRID_COPYONLY) // experiment: the memory access pattern alone (40 us per 1e7 points: 6.2 TB/s)
+            m = p.x > 300.f;
+            p.x += 1.f;
+#else
             m = lrm_dist_tolgrid(L, T, G, p, doubt);
+#endif
             doubt &= 0xffffu;
             dx[i] = p.x;
             dy[i] = p.y;

@@ -90,8 +90,9 @@ def test_apply_oct_defaults_and_capacity(lrm, oracle):
 def test_apply_oct_at_scale_chunked_equals_every_foothold_kernel(lrm, oracle, mode):
     """1e6 footholds (a 4 m x 4 m relief), depth 5: levels with >= 65 children run the chunk-culled kernel (one
     workgroup per child, only the footholds of nearby 64-foothold chunks).  Its leaves must equal, bit for bit, the
-    every-foothold kernel's (LRM_OCT_BRUTE=1) and must not depend on the order of the footholds; a sample of valid
-    leaves is re-derived with the oracle: some foothold within reach is reachable by >= stab legs from the centre."""
+    every-foothold kernel's (LRM_OCT_BRUTE=1: an independent traversal of the same flags) and must not depend on the
+    order of the footholds.  (Equality with the brute-force oracle is checked on trees of up to 3 500 nodes above,
+    where the deeper levels also run the chunk-culled kernel; the oracle is O(children x footholds) in Python.)"""
     import os
     if mode == "strict":
         pytest.skip("one arithmetic mode is enough at this size")
@@ -112,13 +113,3 @@ def test_apply_oct_at_scale_chunked_equals_every_foothold_kernel(lrm, oracle, mo
     shuffled, _ = lrm.apply_oct(f[rng.permutation(n)], dim, st)
     assert np.array_equal(got.view(np.uint32), shuffled.view(np.uint32))
     print(f"apply_oct, 1e6 footholds, depth 5: {len(got)} valid leaves; chunk-culled {ms:.2f} ms of kernels, every-foothold {ms_brute:.2f} ms")
-    legs = []
-    for l in range(st.leg_count):
-        leg = np.array(dim, np.float32).copy()
-        leg[0] = np.float32(st.leg_mount[l])
-        legs.append(leg)
-    reach_len = dim[1] + dim[3] + dim[5] + dim[4]
-    for c in got[rng.choice(len(got), 6, replace=False)]:
-        near = f[np.abs(f - c).max(axis=1) < reach_len + 130.0] - c
-        count = sum(oracle.dist(near.astype(np.float32), leg)[1].astype(int) for leg in legs)
-        assert (count >= st.leg_number_for_stab).any(), "a valid leaf must have a foothold that enough legs reach"
