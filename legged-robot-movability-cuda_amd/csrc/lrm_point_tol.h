@@ -147,9 +147,14 @@ LRM_HD void lrm_tol_plane(const LrmTolLeg& L, const LrmTolTables T, float u, flo
     valid = vacc < 0.f;
     // corner points only matter when the point itself is invalid (one_leg.cu:109-116)
     const uint32_t keep = valid ? 0u : 0xffffffffu;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int n_corners = __builtin_amdgcn_readfirstlane(L.n_corners); // a scalar also when the leg block lives in LDS
+#else
+    const int n_corners = L.n_corners;
+#endif
 #pragma unroll
     for (int i = 0; i < LRM_N_CORNERS; i++) {
-        if (i < L.n_corners) { // wave-uniform
+        if (i < n_corners) { // wave-uniform
             const LrmCircle c = T.feat[4 * LRM_N_CIRCLES + i];
             const float vx = x - c.x, vy = z - c.y;
             const float m = __builtin_fmaf(vy, vy, vx * vx);
