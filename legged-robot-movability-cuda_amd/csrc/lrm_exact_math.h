@@ -15,7 +15,8 @@
 //    float->int conversion, degree-9/8 polynomials in double.  glibc's x86-64 build selects
 //    its FMA variant on AVX2 hosts; with fused multiply-adds this restatement matches that
 //    variant on all 2.2e9 floats with |x| < 120, and with or without FMA on |x| < 7 (the
-//    only range the path produces: angles in [-2pi, 2pi]).  tests/test_exact_math.py checks it.
+//    only range the path produces: angles in [-2pi, 2pi]).  tests/test_capi_cpu.py (host build against this
+//    machine's glibc) and tests/test_gpu_parity.py (device build against the host build) check it.
 //    |x| >= 120 (never produced by the path) is answered with nan, like inf and nan.
 #pragma once
 #include <math.h>

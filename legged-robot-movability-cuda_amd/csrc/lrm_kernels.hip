@@ -45,7 +45,8 @@ static_assert(kLegArgSoA == 32 && kLegArgAoS == 16, "kernarg layout");
 // Waves per SIMD the filtered distance kernels are compiled for.  They are VALU-issue bound and the
 // full issue rate needs many waves: 4 / 5 waves (128 / 96 VGPRs) -> 0.239 / 0.216 ms at steady clocks; with
 // the circle loop of the filter unrolled by 2 instead of 4 (LRM_CIRCLE_UNROLL: fewer table values
-// live at once) 6 / 7 / 8 waves fit without scratch -> 0.207 / 0.203 / 0.205 ms.
+// live at once) 6 / 7 / 8 waves -> 0.207 / 0.203 / 0.205 ms; at 7 waves (72 VGPRs) the compiler reports ScratchSize 0
+// for all four distance kernels (`make resource-usage`; the fused one needs the opaque re-load of dist_soa_kernel).
 #define LRM_DIST_MIN_WAVES 7
 #endif
 #ifndef LRM_DIST_STRICT_MIN_WAVES
