@@ -33,8 +33,9 @@
 // (1 ulp) is <= 8u r from the strict x cos(a) - y sin(a); squared distances by FMA carry 2u relative.  The
 // decision band is the lean reach filter's (LRM_BAND * S-like, >= 4.5x the worst case); ties between two
 // distances taken from the SAME plane point move by at most twice the point's own error, so the tie band is a
-// quarter of the decision band (LRM_TOL_TIE; still >= 2x the worst case; tests/test_tol_cpu.py shrinks the bands
-// until mismatches appear to keep the margin honest).
+// quarter of the decision band (LRM_TOL_TIE; still >= 2x the worst case).  Empirical margin
+// (profiles/r02_tol_band_margin.txt): no mismatch on 3e6 evaluations with the tie band 80x or the decision band 65x
+// smaller than the values in use.
 #pragma once
 #include "lrm_point_fast.h"
 
