@@ -233,6 +233,13 @@ void lrm_octree_default_settings(LrmOctreeSettings* out);
 int lrm_apply_oct(const float* footholds_aos, size_t n, const LrmLegDimensions* dim,
                   const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out,
                   float* ms);
+/* The same tree on `world` GPUs, one process each (the reference is single-device): the children of every level are
+ * dealt round-robin to the ranks and `exchange(flags, n, user)` must replace flags[0..n) by their element-wise MAXIMUM over
+ * all ranks (e.g. an RCCL all-reduce; called once per level by every rank).  Every rank returns all valid leaves. */
+typedef void (*LrmOctExchange)(uint32_t* flags, size_t n, void* user);
+int lrm_apply_oct_sharded(const float* footholds_aos, size_t n, const LrmLegDimensions* dim,
+                          const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out,
+                          float* ms, int rank, int world, LrmOctExchange exchange, void* user);
 const char* lrm_octree_last_error(void);
 
 /* ---- diagnostics -------------------------------------------------------------------------

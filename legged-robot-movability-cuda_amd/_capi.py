@@ -104,6 +104,8 @@ def load():
     L.lrm_apply_oct.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp]
     L.lrm_apply_oct.restype = C.c_int
     L.lrm_octree_last_error.restype = C.c_char_p
+    L.lrm_apply_oct_sharded.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.lrm_apply_oct_sharded.restype = C.c_int
     L.lrm_rotate_leg_data.argtypes = [vp, vp, vp]
     L.lrm_rotate_leg_data.restype = None
     _lib = L
@@ -268,6 +270,34 @@ def apply_oct(footholds, leg, settings=None, capacity=None):
                                   C.addressof(n_out), C.addressof(ms))
         if rc == -1 and n_out.value > cap and capacity is None:
             cap = n_out.value
+            continue
+        if rc != 0:
+            raise LrmError(f"liblrm error {rc}: {load().lrm_octree_last_error().decode()}")
+        return out[: n_out.value].copy(), ms.value
+
+
+OCT_EXCHANGE = C.CFUNCTYPE(None, C.POINTER(C.c_uint32), C.c_size_t, C.c_void_p)
+
+
+def apply_oct_sharded(footholds, leg, settings, rank, world, exchange, capacity=None):
+    """lrm_apply_oct_sharded: `exchange(flags: np.ndarray[uint32])` must replace the array, in place, by its
+    element-wise maximum over all ranks -> (centres float32[k,3], kernel ms); GPU."""
+    footholds = _f32(footholds, (-1, 3))
+    cap = capacity if capacity is not None else 4096
+
+    def _cb(ptr, n, _user):
+        exchange(np.ctypeslib.as_array(ptr, shape=(n,)))
+
+    cb = OCT_EXCHANGE(_cb)
+    while True:
+        out = np.zeros((max(cap, 1), 3), np.float32)
+        n_out = C.c_size_t(0)
+        ms = C.c_float(0)
+        rc = load().lrm_apply_oct_sharded(_ptr(footholds), len(footholds), _ptr(_f32(leg, (14,))),
+                                          None if settings is None else C.addressof(settings), _ptr(out), cap,
+                                          C.addressof(n_out), C.addressof(ms), rank, world, C.cast(cb, C.c_void_p), None)
+        if rc == -1 and n_out.value > cap and capacity is None:
+            cap = n_out.value  # every rank sees the same count and retries together
             continue
         if rc != 0:
             raise LrmError(f"liblrm error {rc}: {load().lrm_octree_last_error().decode()}")

@@ -326,8 +326,18 @@ const char* lrm_octree_last_error(void) { return g_oct_err.c_str(); }
 // apply_oct, several_leg_octree.cu:391-488
 int lrm_apply_oct(const float* footholds, size_t nf, const LrmLegDimensions* dim, const LrmOctreeSettings* st_in,
                   float* centers_out, size_t capacity, size_t* n_out, float* ms) {
+    return lrm_apply_oct_sharded(footholds, nf, dim, st_in, centers_out, capacity, n_out, ms, 0, 1, nullptr, nullptr);
+}
+
+// The same tree on `world` GPUs (one process each): the children of every level are dealt round-robin to the ranks,
+// each rank evaluates its share, and `exchange` combines the flag words (element-wise maximum: every child has exactly
+// one owner, the others contribute 0).  Every rank builds the identical tree and returns all valid leaves.
+int lrm_apply_oct_sharded(const float* footholds, size_t nf, const LrmLegDimensions* dim, const LrmOctreeSettings* st_in,
+                          float* centers_out, size_t capacity, size_t* n_out, float* ms, int rank, int world,
+                          LrmOctExchange exchange, void* user) {
     auto fail = [](int code, const char* w) { g_oct_err = w; return code; };
     if (!dim || !n_out || (nf && !footholds) || (capacity && !centers_out)) return fail(LRM_EINVAL, "null argument");
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !exchange)) return fail(LRM_EINVAL, "bad rank / world / exchange");
     LrmOctreeSettings st;
     if (st_in) st = *st_in;
     else lrm_octree_default_settings(&st);
@@ -460,7 +470,14 @@ int lrm_apply_oct(const float* footholds, size_t nf, const LrmLegDimensions* dim
             OCT_TRY(hipMalloc(&d_flags, nc * sizeof(uint32_t)), "hipMalloc flags");
             children_cap = nc;
         }
-        OCT_TRY(hipMemcpy(d_children, level.data(), nc * sizeof(OctChild), hipMemcpyHostToDevice), "hipMemcpy children");
+        if (world > 1) { // this rank's share of the level: the others' children are skipped on the device only
+            std::vector<OctChild> mine(level);
+            for (size_t k = 0; k < nc; k++)
+                if ((int)(k % (size_t)world) != rank) mine[k].skip = 1;
+            OCT_TRY(hipMemcpy(d_children, mine.data(), nc * sizeof(OctChild), hipMemcpyHostToDevice), "hipMemcpy children");
+        } else {
+            OCT_TRY(hipMemcpy(d_children, level.data(), nc * sizeof(OctChild), hipMemcpyHostToDevice), "hipMemcpy children");
+        }
         OCT_TRY(hipMemset(d_flags, 0, nc * sizeof(uint32_t)), "hipMemset flags");
         std::vector<uint32_t> flags(nc, 0);
         if (nf) {
@@ -496,6 +513,7 @@ int lrm_apply_oct(const float* footholds, size_t nf, const LrmLegDimensions* dim
             OCT_TRY(hipEventElapsedTime(&e, ev_a, ev_b), "hipEventElapsedTime");
             total_ms += e;
         }
+        if (world > 1) exchange(flags.data(), nc, user);
         // several_leg_octree.cu:134-150, with global ORs
         std::vector<int> next;
         for (size_t k = 0; k < nc; k++) {

@@ -230,3 +230,23 @@ def reach_any_target_sharded(bodies, local_targets, legs, quat=None, backend=Non
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         out = t.cpu().numpy()
     return out, out.min(axis=0)
+
+
+def apply_oct_sharded(footholds, leg, settings=None, group=None):
+    """apply_oct (lrm_apply_oct) with the children of every octree level dealt round-robin to the ranks: each rank
+    evaluates its share on its GPU, the per-child flag words are combined with all_reduce(MAX) once per level (every
+    child has one owner, the others contribute 0), and every rank returns all valid leaves.  Each rank holds all
+    footholds.  -> (centres float32[k, 3], this rank's kernel milliseconds)"""
+    import torch
+    from . import _capi
+    dist, world, rank = _dist_info(group)
+    if dist is None or world == 1:
+        return _capi.apply_oct(footholds, leg, settings)
+    dev = _comm_device(dist, group)
+
+    def exchange(flags):  # numpy view of the library's buffer: reduce in place
+        t = torch.from_numpy(flags.astype(np.int32)).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        flags[:] = t.cpu().numpy().astype(np.uint32)
+
+    return _capi.apply_oct_sharded(footholds, leg, settings, rank, world, exchange)

@@ -113,3 +113,42 @@ def test_apply_oct_at_scale_chunked_equals_every_foothold_kernel(lrm, oracle, mo
     shuffled, _ = lrm.apply_oct(f[rng.permutation(n)], dim, st)
     assert np.array_equal(got.view(np.uint32), shuffled.view(np.uint32))
     print(f"apply_oct, 1e6 footholds, depth 5: {len(got)} valid leaves; chunk-culled {ms:.2f} ms of kernels, every-foothold {ms_brute:.2f} ms")
+
+
+def _oct_worker(rank, world, port, ret):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import lrm_amd
+    from test_gpu_octree import footholds, settings
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        f = footholds(3000, seed=9, spread=900.0)
+        dim = lrm_amd.get_M2_leg(0.0)
+        st = settings(lrm_amd, 800.0, 5, stab=3)
+        got, _ = lrm_amd.shard.apply_oct_sharded(f, dim, st)
+        ret[rank] = got.tobytes()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_apply_oct_sharded_over_two_ranks_equals_single_process(lrm):
+    """The level-sharded octree (lrm_apply_oct_sharded: children dealt round-robin, flags combined with all_reduce MAX
+    per level) with two ranks sharing this box's GPU over gloo: both ranks return the single-process leaves."""
+    import os
+    import torch.multiprocessing as mp
+    lrm.set_mode(lrm.MODE_FAST)
+    f = footholds(3000, seed=9, spread=900.0)
+    dim = lrm.get_M2_leg(0.0)
+    st = settings(lrm, 800.0, 5, stab=3)
+    want, _ = lrm.apply_oct(f, dim, st)
+    assert len(want) > 20
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_oct_worker, args=(2, 30500 + os.getpid() % 1000, ret), nprocs=2, join=True)
+    assert ret[0] == want.tobytes() and ret[1] == want.tobytes()
