@@ -121,7 +121,7 @@ bool tol_plane_table_enabled() {
 int launch_dist_mode(int op, const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions& leg,
                      const float* quat, const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                      float* dz, void* stream) {
-    if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xffffffffull) {
+    if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xff000000ull) { // 32-bit point indices in the tolerance kernels (n + one grid stride < 2^32)
         TolEntry& E = tol_entry(leg, quat, L);
         const LrmTolLeg& TL = E.tl;
         if (TL.tol_ok && n >= (size_t)LRM_TOLGRID_MIN_POINTS && tol_plane_table_enabled()) {

@@ -102,10 +102,12 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_kernel(
     }
     const LrmTolTables T{s_tab.circ, s_tab.feat};
 #endif
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    const size_t n_pad = (n + 63) & ~(size_t)63; // whole waves iterate together (ballots below)
+    // 32-bit point indices (the launch function guarantees n + grid stride < 2^32): array addressing is then a
+    // scalar base + a 32-bit VGPR offset instead of a 64-bit v_lshl_add_u64 per access (half-rate)
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t n_pad = (uint32_t)((n + 63) & ~(size_t)63); // whole waves iterate together (ballots below)
     uint32_t* seg = queue + (size_t)blockIdx.x * kSegCap;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
         bool m = false;
         uint32_t doubt = 0;
         if (i < n) {
