@@ -378,8 +378,156 @@ LRM_HD bool lrm_dist_tol_t(const LrmTolLeg& L, const Plane& plane, LrmVec3& p, u
     return fa || fb;
 }
 
+// -------------------------------------------------------------------------------------------------------
+// Staged form of the same evaluation: the more promising yaw candidate first, the second one only when it can
+// still win.  distance_circles (one_leg.cu:321-341) keeps the valid candidate, or the shorter of two invalid ones;
+// only a candidate inside the yaw range can be valid, so that one goes first (else the one whose plane is
+// nearer), and the other is skipped when the first is valid or already shorter than a lower bound of the
+// other's norm: |d|^2 >= w^2 + (|(u - coxa, z)| - r_outer)+^2 (every clamp target lies within r_outer of the femur
+// joint).  About 80 % of the second evaluations of a random cloud go away.  The kernel runs the remaining ones
+// compacted over the workgroup (lrm_tol_kernels.hip): only the PLANE evaluation travels to another lane.
+// -------------------------------------------------------------------------------------------------------
+struct LrmTolPoint {
+    float z, band, tau;
+    float wM, wm;            // offsets from the two yaw-limit planes (the yaw-limit alternative)
+    float c0, s0, u0, w0;    // first candidate: rotation (cos, sin) and plane point (u, z) + offset w
+    float c1, s1, u1, w1;    // second candidate
+    uint32_t lu;             // doubt bits so far
+    bool lim0, lim1;         // the candidate is clamped to a yaw limit
+    bool in0;                // the first candidate lies inside the yaw range (the only kind that can be valid)
+    bool two;                // a second, different candidate exists
+};
+struct LrmTolCand {
+    float X, Y, Z, n; // vector in the coxa frame, squared norm
+    bool flag;        // valid and inside the yaw range
+};
+
+LRM_HD LrmTolPoint lrm_tol_prologue(const LrmTolLeg& L, LrmVec3 p) {
+    LrmTolPoint S;
+    const float* a = L.aff;
+    const float x = __builtin_fmaf(a[0], p.x, __builtin_fmaf(a[1], p.y, __builtin_fmaf(a[2], p.z, a[3])));
+    const float y = __builtin_fmaf(a[4], p.x, __builtin_fmaf(a[5], p.y, __builtin_fmaf(a[6], p.z, a[7])));
+    S.z = __builtin_fmaf(a[8], p.x, __builtin_fmaf(a[9], p.y, __builtin_fmaf(a[10], p.z, a[11])));
+    S.band = __builtin_fmaf(fabsf(p.x) + fabsf(p.y) + fabsf(p.z), L.band_slope, L.band_base);
+    S.tau = S.band * LRM_TOL_TIE;
+    const float m2 = __builtin_fmaf(y, y, x * x);
+    const float rs = LRM_FAST_RSQ(m2);
+    const float r = m2 * rs;
+    const float cu = x * rs, su = y * rs;
+    const float cM = L.yaw_cs[0], sM = L.yaw_cs[1], cm = L.yaw_cs[2], sm = L.yaw_cs[3];
+    const float uM = __builtin_fmaf(x, cM, y * sM), wM = __builtin_fmaf(y, cM, -(x * sM));
+    const float um = __builtin_fmaf(x, cm, y * sm), wm = __builtin_fmaf(y, cm, -(x * sm));
+    S.wM = wM;
+    S.wm = wm;
+    const uint32_t pat = (lrm_f2u(wM) >> 31) | ((lrm_f2u(uM) >> 30) & 2u) | ((lrm_f2u(wm) >> 29) & 4u) |
+                         ((lrm_f2u(um) >> 28) & 8u);
+    constexpr uint32_t kLutD = lrm_tol_lut(false), kLutF = lrm_tol_lut(true);
+    const uint32_t codeD = (kLutD >> (pat << 1)) & 3u, codeF = (kLutF >> (pat << 1)) & 3u;
+    const bool inD = (pat & 5u) == 1u, inF = (pat & 5u) == 4u;
+    const float ymin = fminf(fminf(fabsf(wM), fabsf(uM)), fminf(fabsf(wm), fabsf(um)));
+    S.lu = (!(ymin > S.band) || !(r > LRM_TOL_RMIN)) ? LRM_TD_YAW : 0u;
+    S.two = codeD != codeF;
+    // offsets of the two candidates' planes: 0 for a meridian plane, w of the limit for a limit plane
+    const float wD = codeD >= 2u ? (codeD == 3u ? wm : wM) : 0.f, wF = codeF >= 2u ? (codeF == 3u ? wm : wM) : 0.f;
+    const bool firstD = inD || (!inF && fabsf(wD) <= fabsf(wF));
+    const uint32_t code0 = firstD ? codeD : codeF, code1 = firstD ? codeF : codeD;
+    S.in0 = inD || inF;
+    auto rot = [&](uint32_t code, float& c, float& s, float& u, float& w, bool& lim) {
+        lim = code >= 2u;
+        const bool mn = code == 3u, neg = code == 1u;
+        c = lim ? (mn ? cm : cM) : lrm_u2f(lrm_f2u(cu) ^ (neg ? 0x80000000u : 0u));
+        s = lim ? (mn ? sm : sM) : lrm_u2f(lrm_f2u(su) ^ (neg ? 0x80000000u : 0u));
+        u = __builtin_fmaf(x, c, y * s);
+        w = lim ? __builtin_fmaf(y, c, -(x * s)) : 0.f;
+    };
+    rot(code0, S.c0, S.s0, S.u0, S.w0, S.lim0);
+    rot(code1, S.c1, S.s1, S.u1, S.w1, S.lim1);
+    return S;
+}
+
+// what follows a plane evaluation (du, dz, valid) of candidate `second ? 1 : 0`
+LRM_HD LrmTolCand lrm_tol_candidate(const LrmTolPoint& S, bool second, float du, float dz, bool valid, uint32_t& d) {
+    const bool lim = second ? S.lim1 : S.lim0;
+    const float c = second ? S.c1 : S.c0, s = second ? S.s1 : S.s0, w = second ? S.w1 : S.w0;
+    // a candidate clamped to a yaw limit whose plane point is valid collapses to the offset from that plane, unless
+    // sqrt(du^2 + w^2 + dz^2) rounds to |w| (see lrm_dist_tol_t)
+    if (lim && valid) {
+        const float q = __builtin_fmaf(du, du, dz * dz), w2 = w * w;
+        if (q > w2 * 9.6e-7f) du = dz = 0.f;
+        else if (!(q < w2 * 2.9e-8f)) d |= LRM_TD_LIMIT;
+    }
+    LrmTolCand C;
+    C.X = __builtin_fmaf(du, c, -(w * s));
+    C.Y = __builtin_fmaf(du, s, w * c);
+    C.Z = dz;
+    C.n = __builtin_fmaf(du, du, __builtin_fmaf(w, w, dz * dz));
+    C.flag = valid && !second && S.in0;
+    return C;
+}
+
+// can the second candidate still win against the evaluated first one?
+LRM_HD bool lrm_tol_need_second(const LrmTolLeg& L, const LrmTolPoint& S, const LrmTolCand& A) {
+    const float ux = S.u1 - L.coxa_length;
+    const float out = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(ux, ux, S.z * S.z)) - L.r_outer, 0.f);
+    const float lb = __builtin_fmaf(S.w1, S.w1, out * out);
+    const float thr = S.tau * __builtin_fmaf(2.0f, LRM_FAST_SQRT(A.n), S.tau); // the tie band of the pick, squared domain
+    return S.two && !A.flag && !(A.n < lb - thr);
+}
+
+// yaw-limit alternative of the first candidate, the pick, the way back to the caller's frame
+LRM_HD bool lrm_tol_finish(const LrmTolLeg& L, const LrmTolPoint& S, LrmTolCand A, bool haveB, const LrmTolCand B,
+                           LrmVec3& out, uint32_t& doubt) {
+    uint32_t lu = 0;
+    if (A.flag) { // one_leg.cu:258-274: the nearer limit plane wins over the in-plane boundary when it is closer
+        const float cM = L.yaw_cs[0], sM = L.yaw_cs[1], cm = L.yaw_cs[2], sm = L.yaw_cs[3];
+        const float aM = fabsf(S.wM), am = fabsf(S.wm);
+        const float dl = fminf(aM, am), dl2 = dl * dl;
+        const float thr = S.tau * __builtin_fmaf(2.0f, dl, S.tau);
+        if (!(fabsf(A.n - dl2) > thr) || (!(A.n < dl2 - thr) && !(fabsf(aM - am) > S.tau))) lu |= LRM_TD_LIMIT;
+        if (A.n > dl2) {
+            const bool useM = aM < am;
+            const float wl = useM ? S.wM : S.wm, sl = useM ? sM : sm, cl = useM ? cM : cm;
+            A.X = -(wl * sl);
+            A.Y = wl * cl;
+            A.Z = 0.f;
+            A.n = dl2;
+        }
+    }
+    bool useA = true;
+    if (haveB) { // both invalid (a valid first candidate never asks for the second): the shorter one
+        const float nmin = LRM_FAST_SQRT(fminf(A.n, B.n));
+        const float thr = S.tau * __builtin_fmaf(2.0f, nmin, S.tau);
+        if (!(fabsf(A.n - B.n) > thr)) lu |= LRM_TD_PICK;
+        useA = A.n < B.n;
+    }
+    const float vx = useA ? A.X : B.X, vy = useA ? A.Y : B.Y, vz = useA ? A.Z : B.Z;
+    const float* b = L.back;
+    out.x = __builtin_fmaf(b[0], vx, __builtin_fmaf(b[1], vy, b[2] * vz));
+    out.y = __builtin_fmaf(b[3], vx, __builtin_fmaf(b[4], vy, b[5] * vz));
+    out.z = __builtin_fmaf(b[6], vx, __builtin_fmaf(b[7], vy, b[8] * vz));
+    doubt |= lu;
+    return A.flag;
+}
+
+// the whole evaluation of one point, staged (host builds, the GPU's middle kernel of the plane-table variant)
 LRM_HD bool lrm_dist_tol(const LrmTolLeg& L, const LrmTolTables T, LrmVec3& p, uint32_t& doubt) {
-    return lrm_dist_tol_t(L, LrmTolPlaneFull{L, T}, p, doubt);
+    const LrmTolPoint S = lrm_tol_prologue(L, p);
+    uint32_t lu = S.lu;
+    float du, dz;
+    bool valid;
+    lrm_tol_plane(L, T, S.u0, S.z, S.band, S.tau, du, dz, valid, lu);
+    const LrmTolCand A = lrm_tol_candidate(S, false, du, dz, valid, lu);
+    LrmTolCand B = A;
+    const bool need = lrm_tol_need_second(L, S, A);
+    if (need) {
+        lrm_tol_plane(L, T, S.u1, S.z, S.band, S.tau, du, dz, valid, lu);
+        B = lrm_tol_candidate(S, true, du, dz, valid, lu);
+    }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (need) lu |= LRM_TD_SECOND; // statistic
+#endif
+    doubt |= lu;
+    return lrm_tol_finish(L, S, A, need, B, p, doubt);
 }
 LRM_HD bool lrm_dist_tolgrid(const LrmTolLeg& L, const LrmTolTables T, const LrmTolGridView G, LrmVec3& p, uint32_t& doubt) {
     return lrm_dist_tol_t(L, LrmTolPlaneGrid{L, T, G}, p, doubt);

@@ -27,10 +27,16 @@
 #include "lrm_point_tol.h"
 
 #ifndef LRM_TOL_MIN_WAVES
-#define LRM_TOL_MIN_WAVES 6
+#define LRM_TOL_MIN_WAVES 7 // the staged kernel needs 69 VGPRs; its barriers like occupancy: 6 / 7 / 8 waves -> 116 / 112 / 113 us
 #endif
 #ifndef LRM_TOL_LEG_IN_LDS
 #define LRM_TOL_LEG_IN_LDS 0 // 1: the scalars too go through LDS (full-rate VGPR-only operands by the issue-class table, but measured 148 us against 114: the extra lgkmcnt waits cost more than the half-rate operands)
+#endif
+#ifndef LRM_TOL_BLOCK
+#define LRM_TOL_BLOCK 256
+#endif
+#ifndef LRM_TOL_STAGED
+#define LRM_TOL_STAGED 1
 #endif
 #ifndef LRM_TOL_SEG_PER_WAVE
 #define LRM_TOL_SEG_PER_WAVE 8 // ~30 queued points per fix-up wave at the usual 0.45 % of doubt: one batch
@@ -44,7 +50,7 @@
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = LRM_TOL_BLOCK;
 constexpr int kFixBlock = 64;
 constexpr int kSegCap = LRM_TOL_SEG_CAP;         // doubt slots per workgroup of dist_tol_kernel
 constexpr int kSegPerWave = LRM_TOL_SEG_PER_WAVE;                 // segments one fix-up wave compacts
@@ -142,6 +148,110 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_kernel(
             }
         }
 #endif
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Staged variant (LRM_TOL_STAGED): every lane evaluates the more promising yaw candidate of its point; the lanes
+// whose second candidate can still win (lower bound on its norm, lrm_tol_need_second: ~25 % of a random cloud)
+// hand its PLANE evaluation -- four floats -- to the workgroup through LDS, where it runs compacted (one wave's
+// worth per 256 points instead of all four waves), and take (du, dz, valid, doubt) back.  Everything else, and every
+// global access, stays with the owning lane: coalesced as before.  Two barriers per iteration.
+// ------------------------------------------------------------------------------------------------------------
+template <int kOp>
+__global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
+    const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
+    float* __restrict__ dy, float* __restrict__ dz, uint32_t* __restrict__ queue, uint32_t* __restrict__ counts) {
+    __shared__ TolLds s_tab;
+    __shared__ uint32_t s_qn;
+    __shared__ uint32_t s_cnt[2];
+    __shared__ float4 s_task[kBlock]; // {u, z, band, tau} of a pending second plane evaluation
+    __shared__ float4 s_res[kBlock];  // {du, dz, valid, doubt bits}
+    const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
+    {
+        const float* csrc = reinterpret_cast<const float*>(&L.circ[0][0]);
+        const float* fsrc = reinterpret_cast<const float*>(&L.feat[0]);
+        for (int i = threadIdx.x; i < (int)(sizeof(s_tab.circ) / 4); i += kBlock) reinterpret_cast<float*>(s_tab.circ)[i] = csrc[i];
+        if (threadIdx.x < (int)(sizeof(s_tab.feat) / 4)) reinterpret_cast<float*>(s_tab.feat)[threadIdx.x] = fsrc[threadIdx.x];
+        if (threadIdx.x == 0) { s_qn = 0; s_cnt[0] = 0; s_cnt[1] = 0; }
+        __syncthreads();
+    }
+    const LrmTolTables T{s_tab.circ, s_tab.feat};
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t n_pad = (uint32_t)((n + kBlock - 1) / kBlock) * kBlock; // whole workgroups iterate together (barriers below)
+    uint32_t* seg = queue + (size_t)blockIdx.x * kSegCap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t round = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride, round++) {
+        const bool live = i < n;
+        LrmVec3 p{0.f, 0.f, 0.f};
+        if (live) p = LrmVec3{x[i], y[i], z[i]};
+        // ---- A: first candidate ----
+        const LrmTolPoint S = lrm_tol_prologue(L, p);
+        uint32_t lu = S.lu;
+        float du, dzz;
+        bool valid;
+        lrm_tol_plane(L, T, S.u0, S.z, S.band, S.tau, du, dzz, valid, lu);
+        const LrmTolCand A = lrm_tol_candidate(S, false, du, dzz, valid, lu);
+        const bool need = live && lrm_tol_need_second(L, S, A);
+        // ---- hand the pending second evaluations to the workgroup: slots from an LDS counter (one atomic per wave;
+        // two counters alternate so that resetting one never races with the round that uses the other) ----
+        const uint64_t nm = __ballot(need);
+        uint32_t base = 0;
+        if (lane == 0 && nm) base = atomicAdd(&s_cnt[round & 1u], (uint32_t)__popcll(nm));
+        base = __shfl(base, 0);
+        const uint32_t slot = base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+        if (need) s_task[slot] = make_float4(S.u1, S.z, S.band, S.tau);
+        if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0; // nobody touches the other counter during this round
+        __syncthreads();
+        const uint32_t total = s_cnt[round & 1u];
+        // ---- B: the compacted second plane evaluations; the lanes that take them rotate from round to round ----
+        {
+            const uint32_t t = (threadIdx.x + round * 64u) & (kBlock - 1);
+            if (t < total) {
+                const float4 task = s_task[t];
+                float bu, bz;
+                bool bvalid;
+                uint32_t bd = 0;
+                lrm_tol_plane(L, T, task.x, task.y, task.z, task.w, bu, bz, bvalid, bd);
+                s_res[t] = make_float4(bu, bz, bvalid ? 1.f : 0.f, lrm_u2f(bd));
+            }
+        }
+        __syncthreads();
+        // ---- C: back with the owner ----
+        LrmTolCand B = A;
+        if (need) {
+            const float4 r = s_res[slot];
+            uint32_t bd = lrm_f2u(r.w);
+            B = lrm_tol_candidate(S, true, r.x, r.y, r.z != 0.f, bd);
+            lu |= bd;
+        }
+        uint32_t doubt = lu;
+        const bool m = lrm_tol_finish(L, S, A, need, B, p, doubt) && live;
+        doubt = live ? (doubt & 0xffffu) : 0u;
+        if (live) {
+            dx[i] = p.x;
+            dy[i] = p.y;
+            dz[i] = p.z;
+            if (mask) mask[i] = m;
+        }
+        if (bits && i < (uint32_t)((n + 63) & ~(size_t)63)) { // wave-uniform
+            const uint64_t w = __ballot(m);
+            if (lane == 0) bits[i >> 6] = w;
+        }
+        const uint64_t dm = __ballot(doubt != 0);
+        if (dm) {
+            uint32_t qb = 0;
+            if (lane == 0) qb = atomicAdd(&s_qn, (uint32_t)__popcll(dm));
+            qb = __shfl(qb, 0);
+            if (doubt) {
+                const uint32_t qs = qb + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+                if (qs < (uint32_t)kSegCap) seg[qs] = i;
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
@@ -418,8 +528,13 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
     if (blocks == 0) blocks = 1;
     uint32_t* counts = workspace;
     uint32_t* queue = workspace + cap;
+#if LRM_TOL_STAGED
+    if (op == 2) hipLaunchKernelGGL(dist_tol_staged_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts);
+    else hipLaunchKernelGGL(dist_tol_staged_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts);
+#else
     if (op == 2) hipLaunchKernelGGL(dist_tol_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts);
     else hipLaunchKernelGGL(dist_tol_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts);
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
