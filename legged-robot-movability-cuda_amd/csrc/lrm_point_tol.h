@@ -384,7 +384,11 @@ LRM_HD bool lrm_dist_tol_t(const LrmTolLeg& L, const Plane& plane, LrmVec3& p, u
 // only a candidate inside the yaw range can be valid, so that one goes first (else the one whose plane is
 // nearer), and the other is skipped when the first is valid or already shorter than a lower bound of the
 // other's norm: |d|^2 >= w^2 + (|(u - coxa, z)| - r_outer)+^2 (every clamp target lies within r_outer of the femur
-// joint).  About 80 % of the second evaluations of a random cloud go away.  The kernel runs the remaining ones
+// joint).  About 75 % of the second evaluations of a random cloud go away; what remains is mostly inherent: behind the
+// robot the mirrored yaw is in range, but the limit plane in front is as near as the opposite meridian plane (338 against
+// 336 mm is typical), so whichever goes first the other's bound cannot exclude it.  (Ordering both by their bounds
+// instead: 20 % instead of 26 % second evaluations, but 16 more instructions for every point -- 113 us against 111.)
+// The kernel runs the remaining ones
 // compacted over the workgroup (lrm_tol_kernels.hip): only the PLANE evaluation travels to another lane.
 // -------------------------------------------------------------------------------------------------------
 struct LrmTolPoint {
