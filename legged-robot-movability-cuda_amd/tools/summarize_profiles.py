@@ -18,7 +18,7 @@ import re
 import sys
 
 STEP_KERNELS = {
-    "tol": ["dist_tol_kernel<2>", "tol_fixup_kernel<2>"],
+    "tol": ["dist_tol_staged_kernel<2>", "dist_tol_kernel<2>", "tol_fixup_kernel<2>"],  # whichever main kernel the build launches
     "fast": ["dist_soa_kernel<2, true>"],
     "strict": ["dist_soa_kernel<2, false>"],
 }
