@@ -85,6 +85,28 @@
 #endif
 #define LRM_TD_SECOND 0x10000u // statistic only: the second candidate could not be pruned by its lower bound
 
+#ifndef LRM_TOL_DIET
+#define LRM_TOL_DIET 1
+#endif
+// min(|a|, |b|, c) and max(a, |b|) as ONE instruction each: fminf(fabsf(a), fabsf(b)) compiles to a canonicalising
+// v_max_f32 per operand in front of the v_min_f32 (IEEE mode), six instructions for a four-way minimum instead of two.
+// NaN operands are ignored, exactly as fminf / fmaxf ignore them.
+#if defined(__HIP_DEVICE_COMPILE__) && LRM_TOL_DIET
+__device__ __forceinline__ float lrm_min3_aa(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float lrm_max_a(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#else
+LRM_HD float lrm_min3_aa(float a, float b, float c) { return fminf(fminf(fabsf(a), fabsf(b)), c); }
+LRM_HD float lrm_max_a(float a, float b) { return fmaxf(a, fabsf(b)); }
+#endif
+
 struct LrmTolTables {
     const LrmTolLeg::Circle* circ; // [16]
     const LrmCircle* feat;         // [LRM_TOL_FEATS]
@@ -119,7 +141,11 @@ LRM_HD void lrm_tol_plane(const LrmTolLeg& L, const LrmTolTables T, float u, flo
     const float t_s0 = __builtin_fmaf(L.dir_cos[1], z, -(L.dir_sin[1] * x));
     const float t_s1 = __builtin_fmaf(L.dir_cos[2], z, -(L.dir_sin[2] * x));
     const uint32_t reg = lrm_region_from_signs(L.region_lut, t_mid, t_s0, t_s1, z) * LRM_N_CIRCLES;
-    float macc = fminf(fminf(fabsf(t_mid), fabsf(t_s0)), fminf(fabsf(t_s1), fmaxf(x, fabsf(z))));
+#if LRM_TOL_DIET
+    const float macc = lrm_min3_aa(t_s1, t_s1, lrm_min3_aa(t_mid, t_s0, lrm_max_a(x, z)));
+#else
+    const float macc = fminf(fminf(fabsf(t_mid), fabsf(t_s0)), fminf(fabsf(t_s1), fmaxf(x, fabsf(z))));
+#endif
     float vacc = -3.0e38f, cacc = 3.0e38f;
     uint32_t lo = 0x7f80000fu, hi = 0x7f80000fu; // the two smallest keys: squared distance bits | candidate number
     const LrmTolLeg::Circle* ct = T.circ + reg;
@@ -147,7 +173,11 @@ LRM_HD void lrm_tol_plane(const LrmTolLeg& L, const LrmTolTables T, float u, flo
     }
     valid = vacc < 0.f;
     // corner points only matter when the point itself is invalid (one_leg.cu:109-116)
+#if LRM_TOL_DIET
+    const uint32_t lo_circ = lo, hi_circ = hi; // ranking without the corner points: selected again after the loop
+#else
     const uint32_t keep = valid ? 0u : 0xffffffffu;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     const int n_corners = __builtin_amdgcn_readfirstlane(L.n_corners); // a scalar also when the leg block lives in LDS
 #else
@@ -160,11 +190,17 @@ LRM_HD void lrm_tol_plane(const LrmTolLeg& L, const LrmTolTables T, float u, flo
             const float vx = x - c.x, vy = z - c.y;
             const float m = __builtin_fmaf(vy, vy, vx * vx);
             uint32_t k = (lrm_f2u(m) & ~15u) | (uint32_t)(LRM_N_CIRCLES + i);
+#if !LRM_TOL_DIET
             k = (k & keep) | (0x7f80000fu & ~keep);
+#endif
             hi = lrm_umed3(lo, hi, k);
             lo = lo < k ? lo : k;
         }
     }
+#if LRM_TOL_DIET
+    lo = valid ? lo_circ : lo;
+    hi = valid ? hi_circ : hi;
+#endif
     const float lo2 = lrm_u2f(lo & ~15u), hi2 = lrm_u2f(hi & ~15u);
     // |b - a| < tau  <=>  b^2 < a^2 + tau (2a + tau); the keys dropped 4 mantissa bits (< 2e-6 relative)
     const float a = LRM_FAST_SQRT(lo2);
@@ -428,7 +464,11 @@ LRM_HD LrmTolPoint lrm_tol_prologue(const LrmTolLeg& L, LrmVec3 p) {
     constexpr uint32_t kLutD = lrm_tol_lut(false), kLutF = lrm_tol_lut(true);
     const uint32_t codeD = (kLutD >> (pat << 1)) & 3u, codeF = (kLutF >> (pat << 1)) & 3u;
     const bool inD = (pat & 5u) == 1u, inF = (pat & 5u) == 4u;
+#if LRM_TOL_DIET
+    const float ymin = lrm_min3_aa(wm, um, lrm_min3_aa(wM, uM, 3.0e38f));
+#else
     const float ymin = fminf(fminf(fabsf(wM), fabsf(uM)), fminf(fabsf(wm), fabsf(um)));
+#endif
     S.lu = (!(ymin > S.band) || !(r > LRM_TOL_RMIN)) ? LRM_TD_YAW : 0u;
     S.two = codeD != codeF;
     // offsets of the two candidates' planes: 0 for a meridian plane, w of the limit for a limit plane

@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "lrm_launch.h"
 #include "lrm_types.h"
 #define LRM_FRESH(L) lrm_fresh(L)
@@ -27,7 +28,7 @@
 #include "lrm_point_tol.h"
 
 #ifndef LRM_TOL_MIN_WAVES
-#define LRM_TOL_MIN_WAVES 7 // the staged kernel needs 69 VGPRs; its barriers like occupancy: 6 / 7 / 8 waves -> 116 / 112 / 113 us
+#define LRM_TOL_MIN_WAVES 8 // the staged kernel needs 59 VGPRs; its barriers like occupancy: 6 / 7 / 8 waves -> 123.0 / 122.3 / 119.9 us per step
 #endif
 #ifndef LRM_TOL_LEG_IN_LDS
 #define LRM_TOL_LEG_IN_LDS 0 // 1: the scalars too go through LDS (full-rate VGPR-only operands by the issue-class table, but measured 148 us against 114: the extra lgkmcnt waits cost more than the half-rate operands)
@@ -68,6 +69,21 @@ struct KernargFix {
 constexpr unsigned kTolLegArg = (unsigned)offsetof(KernargTol, L), kFixLegArg = (unsigned)offsetof(KernargFix, L);
 static_assert(kTolLegArg == 32 && kFixLegArg == 32, "kernarg layout");
 
+// element at BYTE offset `off` (32 bits, zero-extended) of the global array p.  With a wave-uniform p and an offset the
+// optimiser cannot see through (lrm_opaque below) the access is "scalar base + 32-bit vector offset"; otherwise the
+// loop-invariant base + thread part is hoisted into a 64-bit VGPR pair per array and the round offset is added with one
+// v_lshl_add_u64 per access.
+#define LRM_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ LRM_GLOBAL T& lrm_at(T* p, uint32_t off) {
+    using C = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+    return *(LRM_GLOBAL T*)((LRM_GLOBAL C*)p + off);
+}
+__device__ __forceinline__ uint32_t lrm_opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 struct TolLds {
     LrmTolLeg::Circle circ[16];
     LrmCircle feat[LRM_TOL_FEATS];
@@ -76,7 +92,7 @@ struct TolLds {
 // kOp 1: distance + optional validity byte; kOp 2: reach mask (+ bit words) + distance.  In this mode the two
 // flags are the same function of the point wherever no decision is in doubt.
 template <int kOp>
-__global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_kernel(
+__global__ __launch_bounds__(kBlock, 7) void dist_tol_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, uint32_t* __restrict__ queue, uint32_t* __restrict__ counts) {
@@ -184,11 +200,16 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
     const uint32_t n_pad = (uint32_t)((n + kBlock - 1) / kBlock) * kBlock; // whole workgroups iterate together (barriers below)
     uint32_t* seg = queue + (size_t)blockIdx.x * kSegCap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t toff0 = threadIdx.x * 4u;
     uint32_t round = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride, round++) {
         const bool live = i < n;
+        // Addresses as (wave-uniform base of this round) + threadIdx.x: the base lives in SGPRs and advances on the
+        // scalar unit, the vector offset is a loop invariant -- no 64-bit address arithmetic on the vector unit
+        const size_t rbase = (size_t)blockIdx.x * kBlock + (size_t)round * stride;
+        const uint32_t toff = lrm_opaque(toff0), tid_o = lrm_opaque(threadIdx.x);
         LrmVec3 p{0.f, 0.f, 0.f};
-        if (live) p = LrmVec3{x[i], y[i], z[i]};
+        if (live) p = LrmVec3{lrm_at(x + rbase, toff), lrm_at(y + rbase, toff), lrm_at(z + rbase, toff)};
         // ---- A: first candidate ----
         const LrmTolPoint S = lrm_tol_prologue(L, p);
         uint32_t lu = S.lu;
@@ -202,7 +223,7 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         const uint64_t nm = __ballot(need);
         uint32_t base = 0;
         if (lane == 0 && nm) base = atomicAdd(&s_cnt[round & 1u], (uint32_t)__popcll(nm));
-        base = __shfl(base, 0);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         const uint32_t slot = base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
         if (need) s_task[slot] = make_float4(S.u1, S.z, S.band, S.tau);
         if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0; // nobody touches the other counter during this round
@@ -233,20 +254,20 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         const bool m = lrm_tol_finish(L, S, A, need, B, p, doubt) && live;
         doubt = live ? (doubt & 0xffffu) : 0u;
         if (live) {
-            dx[i] = p.x;
-            dy[i] = p.y;
-            dz[i] = p.z;
-            if (mask) mask[i] = m;
+            lrm_at(dx + rbase, toff) = p.x;
+            lrm_at(dy + rbase, toff) = p.y;
+            lrm_at(dz + rbase, toff) = p.z;
+            if (mask) lrm_at(mask + rbase, tid_o) = m;
         }
         if (bits && i < (uint32_t)((n + 63) & ~(size_t)63)) { // wave-uniform
             const uint64_t w = __ballot(m);
-            if (lane == 0) bits[i >> 6] = w;
+            if (lane == 0) lrm_at(bits + (rbase >> 6), lrm_opaque((uint32_t)wave * 8u)) = w;
         }
         const uint64_t dm = __ballot(doubt != 0);
         if (dm) {
             uint32_t qb = 0;
             if (lane == 0) qb = atomicAdd(&s_qn, (uint32_t)__popcll(dm));
-            qb = __shfl(qb, 0);
+            qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
             if (doubt) {
                 const uint32_t qs = qb + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
                 if (qs < (uint32_t)kSegCap) seg[qs] = i;

@@ -52,6 +52,17 @@ def main():
                 out["tol_queue_counts(points, full, exact)"] = lrm_amd.dbg_tol_queue_counts()
             except Exception as e:  # below the plane-table threshold
                 out["tol_queue_counts"] = str(e)
+        if name == "tol":  # the variant under test against the bit-exact mode, on the device
+            lrm_amd.set_mode(lrm_amd.MODE_FAST)
+            m2 = torch.empty_like(mask)
+            f2 = torch.empty_like(field)
+            b2 = torch.empty_like(bits)
+            lrm_amd.device.reach_dist(x, y, z, leg, None, mask=m2, out=f2, bits=b2)
+            lrm_amd.set_mode(modes[name])
+            err = (field - f2).norm(dim=0) / torch.maximum(f2.norm(dim=0), cloud.norm(dim=0) / 8)
+            out["tol_check"] = {"mask_mismatches": int((mask != m2).sum()), "bit_word_mismatches": int((bits != b2).sum()),
+                                "max_err": float(err.max()), "nonfinite": int((~torch.isfinite(field)).sum())}
+            del m2, f2, b2, err
         out[name] = {"ms_per_call": ms, "evals_per_s": n / (ms * 1e-3), "hbm_GBs_algorithmic": 25 * n / (ms * 1e-3) / 1e9,
                      "frac_of_8TBs": 25 * n / (ms * 1e-3) / 8e12}
     lrm_amd.set_mode(lrm_amd.MODE_FAST)
