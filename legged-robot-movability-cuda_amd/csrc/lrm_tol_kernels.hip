@@ -49,6 +49,22 @@
 #define LRM_TOL_GRID_MULT 8
 #endif
 
+#if defined(LRM_FIX_TRACE)
+// timing experiment (tools/fix_trace.py): s_memrealtime stamps (100 MHz) of the phases of the fix-up waves and the
+// end of every workgroup of the main kernel
+__device__ uint64_t g_fix_trace[8 * 4096];
+__device__ uint64_t g_main_trace[2 * 32768];
+extern "C" int lrm_dbg_fix_trace(uint64_t* fix_out, uint64_t* main_out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(fix_out, HIP_SYMBOL(g_fix_trace), sizeof(g_fix_trace)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(main_out, HIP_SYMBOL(g_main_trace), sizeof(g_main_trace)) != hipSuccess) return -1;
+    return 0;
+}
+#define LRM_TRACE_FIX(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_fix_trace[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define LRM_TRACE_FIX(k) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int kBlock = LRM_TOL_BLOCK;
@@ -201,6 +217,9 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
     uint32_t* seg = queue + (size_t)blockIdx.x * kSegCap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t toff0 = threadIdx.x * 4u;
+#if defined(LRM_FIX_TRACE)
+    if (threadIdx.x == 0 && blockIdx.x < 32768) g_main_trace[blockIdx.x * 2] = wall_clock64();
+#endif
     uint32_t round = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride, round++) {
         const bool live = i < n;
@@ -276,6 +295,9 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
     }
     __syncthreads();
     if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
+#if defined(LRM_FIX_TRACE)
+    if (threadIdx.x == 0 && blockIdx.x < 32768) g_main_trace[blockIdx.x * 2 + 1] = wall_clock64();
+#endif
 }
 
 // Bit i of the ballot words an earlier launch wrote becomes `m`.  Only this lane ever changes that bit, so a plain
@@ -288,6 +310,63 @@ __device__ __forceinline__ void patch_bit(uint64_t* bits, size_t i, bool m) {
     if (cur == m) return;
     if (m) atomicOr(w, bit);
     else atomicAnd(w, ~bit);
+}
+
+#ifndef LRM_TOL_FIX_PAIR
+#define LRM_TOL_FIX_PAIR 1
+#endif
+// The fix-up launch is one latency chain per wave (tools/fix_trace.py: 2.4 us launch gap, 2.3 us tables / counts /
+// prefix, then ~1000 dependent instructions of the filtered code at one wave per SIMD, 6.6 us -- 14.7 us where a lane
+// needs the strict plane evaluation), and its waves are mostly empty (13 queued points on average).  So a point takes TWO
+// lanes: lane ^ 1 holds the same point and each lane evaluates ONE of the two yaw candidates of distance_circles
+// (one_leg.cu:321-341), half the chain; the results change lanes with one DPP move each.  Same operations in the same
+// order as lrm_reach_dist_global_filtered / lrm_dist_global_filtered: bit-identical results.
+__device__ __forceinline__ uint32_t lrm_pair_swap(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ float lrm_pair_swap(float v) { return lrm_u2f(lrm_pair_swap(lrm_f2u(v))); }
+
+template <int kOp>
+__device__ __forceinline__ bool lrm_redo_pair(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& p, int cand) {
+    const LrmVec3 p_in = p;
+    // lrm_dist_global_fast
+    LrmVec3 u = lrm_qrot(L.inv_rot, p);
+    float buffer = u.x * L.sin_body;
+    u.x = u.x * L.cos_body - u.y * L.sin_body;
+    u.y = buffer + u.y * L.cos_body;
+    // lrm_dist_circles_fast, one candidate per lane
+    LrmVec3 mine = u;
+    mine.x -= L.body;
+    buffer = mine.x * L.sin_pitch;
+    mine.x = mine.x * L.cos_pitch - mine.z * L.sin_pitch;
+    mine.z = buffer + mine.z * L.cos_pitch;
+    const float ax = mine.x;
+    const float ang = lrm_atan2f(mine.y, mine.x);
+    const float ang_flip = (ang > 0) ? ang - LRM_PI_F : ang + LRM_PI_F;
+    uint32_t u_mine = 0;
+    const bool r_mine = lrm_finish_closest_fast(LRM_FRESH(L), T, mine, cand ? ang_flip : ang, u_mine);
+    const LrmVec3 other{lrm_pair_swap(mine.x), lrm_pair_swap(mine.y), lrm_pair_swap(mine.z)};
+    const bool r_other = lrm_pair_swap(r_mine ? 1u : 0u) != 0u;
+    const uint32_t u_other = lrm_pair_swap(u_mine);
+    const LrmVec3 a = cand ? other : mine, b = cand ? mine : other;
+    const bool res = cand ? r_other : r_mine, resflip = cand ? r_mine : r_other;
+    const bool use_direct = (res == resflip) ? (lrm_norm3(a) < lrm_norm3(b)) : res;
+    LrmVec3 r = use_direct ? a : b;
+    const LrmCompiledLeg& Le = LRM_FRESH(L);
+    buffer = r.x * Le.sin_pitch_rev;
+    r.x = r.x * Le.cos_pitch_rev - r.z * Le.sin_pitch_rev;
+    r.z = buffer + r.z * Le.cos_pitch_rev;
+    buffer = r.x * -Le.sin_body;
+    r.x = r.x * Le.cos_body - r.y * -Le.sin_body;
+    r.y = buffer + r.y * Le.cos_body;
+    p = lrm_qrot(Le.fwd_rot, r);
+    if (kOp != 2) return res || resflip;
+    // lrm_reach_dist_global_filtered: the mask out of the distance's by-products
+    const LrmDistByproduct by{res, resflip, cand ? u_mine : u_other, ax, ang, ang_flip};
+    bool doubt;
+    bool reach = lrm_reach_from_dist(L, by, doubt);
+    if (doubt) reach = lrm_reach_global(L, T.lists, p_in);
+    return reach;
 }
 
 struct FixLds {
@@ -309,6 +388,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kFixLegArg);
     const uint32_t seg0 = blockIdx.x * kSegPerWave;
     const int lane = threadIdx.x;
+    LRM_TRACE_FIX(0);
     // This kernel is a chain of latencies (launch, counts, tables, gather, ~2000 dependent instructions of the exact
     // code at one wave per SIMD): the table loads (16 bytes per lane and pass) go out first, the counts behind them.
     static_assert(sizeof(s_tab.lists) % 16 == 0 && sizeof(s_tab.dist) % 16 == 0 && sizeof(s_tab.corners) % 16 == 0, "16-byte staging");
@@ -322,6 +402,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     }
     if (lane < kSegPerWave) s_cnt[lane] = (seg0 + lane < nseg) ? counts[seg0 + lane] : 0u;
     __syncthreads();
+    LRM_TRACE_FIX(1);
     if (lane == 0) {
         uint32_t acc = 0;
         for (int j = 0; j < kSegPerWave; j++) {
@@ -335,6 +416,23 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     if (any == 0) return; // nothing in doubt in these workgroups (wave-uniform)
     __syncthreads();
     const LrmDistTables T{s_tab.lists, s_tab.dist, s_tab.corners};
+#if LRM_TOL_FIX_PAIR
+    constexpr int kPerPass = kFixBlock / 2; // points per pass of the wave
+    const int slot = lane >> 1, cand = lane & 1;
+    auto redo = [&](size_t i) { // both lanes of the pair come here with the same i
+        LrmVec3 p{x[i], y[i], z[i]};
+        const bool m = lrm_redo_pair<kOp>(L, T, p, cand);
+        if (cand == 0) {
+            dx[i] = p.x;
+            dy[i] = p.y;
+            dz[i] = p.z;
+            if (mask) mask[i] = m;
+            if (bits) patch_bit(bits, i, m);
+        }
+    };
+#else
+    constexpr int kPerPass = kFixBlock;
+    const int slot = lane;
     auto redo = [&](size_t i) {
         LrmVec3 p{x[i], y[i], z[i]};
         bool m = false;
@@ -346,18 +444,30 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
         if (mask) mask[i] = m;
         if (bits) patch_bit(bits, i, m);
     };
+#endif
     const uint32_t total = s_pre[kSegPerWave];
-    for (uint32_t k = lane; k < total; k += kFixBlock) {
+    LRM_TRACE_FIX(2);
+#if defined(LRM_FIX_TRACE)
+    int pass = 0;
+#endif
+    for (uint32_t k = slot; k < total; k += kPerPass) {
         int j = 0;
 #pragma unroll
         for (int t = 1; t < kSegPerWave; t++) j += (s_pre[t] <= k) ? 1 : 0; // segments with nothing queued share a prefix
         redo((size_t)queue[(size_t)(seg0 + j) * seg_cap + (k - s_pre[j])]);
+#if defined(LRM_FIX_TRACE)
+        if (lane == 0 && pass < 4 && blockIdx.x < 4096) g_fix_trace[blockIdx.x * 8 + 3 + pass] = wall_clock64();
+        pass++;
+#endif
     }
+#if defined(LRM_FIX_TRACE)
+    if (lane == 0 && blockIdx.x < 4096) g_fix_trace[blockIdx.x * 8 + 7] = total;
+#endif
     for (int j = 0; j < kSegPerWave; j++) {
         if (s_cnt[j] <= seg_cap || main_stride == 0) continue; // wave-uniform (only dist_tol_kernel's fixed-size segments can overflow)
         // every point of workgroup seg0 + j: i = (seg0 + j) * kBlock + t + round * main_stride
         for (size_t base = (size_t)(seg0 + j) * kBlock; base < n; base += main_stride)
-            for (int t = lane; t < kBlock; t += kFixBlock)
+            for (int t = slot; t < kBlock; t += kPerPass)
                 if (base + t < n) redo(base + t);
     }
 }
