@@ -246,8 +246,14 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         const uint32_t slot = base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
         if (need) s_task[slot] = make_float4(S.u1, S.z, S.band, S.tau);
         if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0; // nobody touches the other counter during this round
+#if !defined(LRM_TOL_EXP_NOBARRIER) // timing experiments only (wrong results)
         __syncthreads();
+#endif
+#if defined(LRM_TOL_EXP_NOB)
+        const uint32_t total = 0;
+#else
         const uint32_t total = s_cnt[round & 1u];
+#endif
         // ---- B: the compacted second plane evaluations; the lanes that take them rotate from round to round ----
         {
             const uint32_t t = (threadIdx.x + round * 64u) & (kBlock - 1);
@@ -260,7 +266,9 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
                 s_res[t] = make_float4(bu, bz, bvalid ? 1.f : 0.f, lrm_u2f(bd));
             }
         }
+#if !defined(LRM_TOL_EXP_NOBARRIER)
         __syncthreads();
+#endif
         // ---- C: back with the owner ----
         LrmTolCand B = A;
         if (need) {
