@@ -240,6 +240,12 @@ typedef void (*LrmOctExchange)(uint32_t* flags, size_t n, void* user);
 int lrm_apply_oct_sharded(const float* footholds_aos, size_t n, const LrmLegDimensions* dim,
                           const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out,
                           float* ms, int rank, int world, LrmOctExchange exchange, void* user);
+/* The same with the footholds already on the device, one array per component (the layout of the other *_dev entry points;
+ * the reference has no such call: apply_oct uploads its Array<float3> every time, several_leg_octree.cu:408-414).  The arrays
+ * are read only (a sorted copy is made).  rank / world / exchange as lrm_apply_oct_sharded (0, 1, NULL, NULL on one GPU). */
+int lrm_apply_oct_dev(const float* fx, const float* fy, const float* fz, size_t n, const LrmLegDimensions* dim,
+                      const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out, float* ms,
+                      int rank, int world, LrmOctExchange exchange, void* user);
 const char* lrm_octree_last_error(void);
 
 /* ---- diagnostics -------------------------------------------------------------------------

@@ -106,6 +106,8 @@ def load():
     L.lrm_octree_last_error.restype = C.c_char_p
     L.lrm_apply_oct_sharded.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, C.c_int, C.c_int, vp, vp]
     L.lrm_apply_oct_sharded.restype = C.c_int
+    L.lrm_apply_oct_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.lrm_apply_oct_dev.restype = C.c_int
     L.lrm_rotate_leg_data.argtypes = [vp, vp, vp]
     L.lrm_rotate_leg_data.restype = None
     _lib = L
@@ -260,7 +262,7 @@ def octree_default_settings():
 def apply_oct(footholds, leg, settings=None, capacity=None):
     """apply_oct (several_leg_octree.cu:391-488) -> (centres float32[k,3], kernel ms); GPU."""
     footholds = _f32(footholds, (-1, 3))
-    cap = capacity if capacity is not None else 4096
+    cap = capacity if capacity is not None else 65536  # valid leaves; a larger tree makes the call run twice
     while True:
         out = np.zeros((max(cap, 1), 3), np.float32)
         n_out = C.c_size_t(0)
@@ -279,11 +281,35 @@ def apply_oct(footholds, leg, settings=None, capacity=None):
 OCT_EXCHANGE = C.CFUNCTYPE(None, C.POINTER(C.c_uint32), C.c_size_t, C.c_void_p)
 
 
+def apply_oct_dev(x_ptr, y_ptr, z_ptr, n, leg, settings=None, rank=0, world=1, exchange=None, capacity=None):
+    """lrm_apply_oct_dev: the footholds as three device arrays (raw pointers) -> (centres float32[k,3], kernel ms)."""
+    cap = capacity if capacity is not None else 65536  # valid leaves; a larger tree makes the call run twice
+
+    def _cb(ptr, m, _user):
+        exchange(np.ctypeslib.as_array(ptr, shape=(m,)))
+
+    cb = OCT_EXCHANGE(_cb) if exchange is not None else None
+    while True:
+        out = np.zeros((max(cap, 1), 3), np.float32)
+        n_out = C.c_size_t(0)
+        ms = C.c_float(0)
+        rc = load().lrm_apply_oct_dev(x_ptr, y_ptr, z_ptr, n, _ptr(_f32(leg, (14,))),
+                                      None if settings is None else C.addressof(settings), _ptr(out), cap,
+                                      C.addressof(n_out), C.addressof(ms), rank, world,
+                                      C.cast(cb, C.c_void_p) if cb is not None else None, None)
+        if rc == -1 and n_out.value > cap and capacity is None:
+            cap = n_out.value
+            continue
+        if rc != 0:
+            raise LrmError(f"liblrm error {rc}: {load().lrm_octree_last_error().decode()}")
+        return out[: n_out.value].copy(), ms.value
+
+
 def apply_oct_sharded(footholds, leg, settings, rank, world, exchange, capacity=None):
     """lrm_apply_oct_sharded: `exchange(flags: np.ndarray[uint32])` must replace the array, in place, by its
     element-wise maximum over all ranks -> (centres float32[k,3], kernel ms); GPU."""
     footholds = _f32(footholds, (-1, 3))
-    cap = capacity if capacity is not None else 4096
+    cap = capacity if capacity is not None else 65536  # valid leaves; a larger tree makes the call run twice
 
     def _cb(ptr, n, _user):
         exchange(np.ctypeslib.as_array(ptr, shape=(n,)))

@@ -22,9 +22,11 @@
 // committed.  No reference run exists for this path: parity is pinned by composition of the pinned
 // distance_global only, against tests/octree_oracle.py.)
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -54,15 +56,61 @@ __device__ __forceinline__ bool in_box(LrmVec3 v, float hx, float hy, float hz) 
     return hx >= v.x && hy >= v.y && hz >= v.z && -hx < v.x && -hy < v.y && -hz < v.z;
 }
 
+// One (child, foothold) work item: the flags it contributes (1 reach, 2 valid leaf, 4 edge), validity_child
+// several_leg_octree.cu:84-131.
+// Exact cull in front of the distance evaluations: a leg can only reach the foothold, and its distance vector can only
+// fall inside the child box, when the foothold is within hd = |half size| (+ margin) of the bounding sphere of everything
+// that leg reaches (`spheres`, from LrmCompiledLeg::pair_center / pair_r2 turned into this frame: the nearest boundary
+// point lies in the closure of the reachable set, so |distance vector| >= distance to the sphere).  With `near` such legs,
+// reach_count <= near and cross_count <= near: when near < LegNumberForStab and near <= LegCount - LegNumberForStab the
+// item contributes `reach = parent_valid`, no edge -- without evaluating anything.  Deep in the tree (small boxes, four
+// legs mounted 45 degrees apart) that is most of the footholds inside the elongated parent box.
+template <bool kFast>
+__device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 vect, float h2, float hd, const LrmCompiledLeg* __restrict__ legs,
+                                                   const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float convex_r2) {
+    uint32_t mine = 0;
+    for (int a = 0; a < ch.n_angles; a++) {
+        int near = 0;
+        for (int l = 0; l < leg_count; l++) {
+            const float4 sp = spheres[a * leg_count + l];
+            const float ex = vect.x - sp.x, ey = vect.y - sp.y, ez = vect.z - sp.z, rr = sp.w + hd;
+            near += (ex * ex + ey * ey + ez * ez < rr * rr) ? 1 : 0;
+        }
+        if (near < legs_for_stab && near <= leg_count - legs_for_stab) {
+            mine |= ch.parent_valid ? 3u : 0u;
+            continue;
+        }
+        int reach_count = 0, cross_count = 0;
+        for (int l = 0; l < leg_count; l++) {
+            const LrmCompiledLeg& L = legs[a * leg_count + l];
+            LrmVec3 v = vect;
+            bool sub;
+            if (kFast) sub = lrm_dist_global_filtered(L, LrmDistTables{&L.lists[0][0], &L.dist_tab[0][0], &L.corner_tab[0]}, v);
+            else sub = lrm_dist_global(L, &L.lists[0][0], v);
+            bool cross;
+            if (h2 > convex_r2) cross = in_box(v, ch.h[0], ch.h[1], ch.h[2]);   // :103-107 (margin unused there)
+            else cross = (v.x * v.x + v.y * v.y + v.z * v.z) < h2 + ch.margin;  // :108-109
+            cross_count += cross;
+            reach_count += sub;
+        }
+        const bool edge = cross_count > leg_count - legs_for_stab;
+        const bool reach = ch.parent_valid || (reach_count >= legs_for_stab);
+        mine |= (reach ? 1u : 0u) | ((reach && !edge) ? 2u : 0u) | (edge ? 4u : 0u);
+    }
+    return mine;
+}
+
 template <bool kFast>
 __global__ __launch_bounds__(kOctBlock) void oct_validity_kernel(
     const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
     const float* __restrict__ fy, const float* __restrict__ fz, size_t nf,
-    const LrmCompiledLeg* __restrict__ legs /* [n_angles_max][leg_count] */, int leg_count, int legs_for_stab,
+    const LrmCompiledLeg* __restrict__ legs /* [n_angles_max][leg_count] */, const float4* __restrict__ spheres /* same shape */,
+    int leg_count, int legs_for_stab,
     float reach_len, float convex_r2, uint32_t* __restrict__ flags /* per child: 1 reach, 2 valid leaf, 4 edge */) {
     const OctChild ch = children[blockIdx.y];
     if (ch.skip) return;
     const float h2 = ch.h[0] * ch.h[0] + ch.h[1] * ch.h[1] + ch.h[2] * ch.h[2]; // linormRaw(topOffset)
+    const float hd = sqrtf(h2 + fmaxf(ch.margin, 0.f)) * 1.0001f + 0.01f; // the longest distance vector that can "cross" this child
     uint32_t mine = 0, published = 0;
     const size_t stride = (size_t)gridDim.x * kOctBlock;
     const size_t nf_pad = (nf + 63) & ~(size_t)63;
@@ -79,24 +127,7 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_kernel(
         const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
         // elongated parent box, several_leg_octree.cu:76-82
         if (!in_box(vect, ch.ph[0] + reach_len, ch.ph[1] + reach_len, ch.ph[2] + reach_len)) continue;
-        for (int a = 0; a < ch.n_angles; a++) {
-            int reach_count = 0, cross_count = 0;
-            for (int l = 0; l < leg_count; l++) {
-                const LrmCompiledLeg& L = legs[a * leg_count + l];
-                LrmVec3 v = vect;
-                bool sub;
-                if (kFast) sub = lrm_dist_global_filtered(L, LrmDistTables{&L.lists[0][0], &L.dist_tab[0][0], &L.corner_tab[0]}, v);
-                else sub = lrm_dist_global(L, &L.lists[0][0], v);
-                bool cross;
-                if (h2 > convex_r2) cross = in_box(v, ch.h[0], ch.h[1], ch.h[2]);   // :103-107 (margin unused there)
-                else cross = (v.x * v.x + v.y * v.y + v.z * v.z) < h2 + ch.margin;  // :108-109
-                cross_count += cross;
-                reach_count += sub;
-            }
-            const bool edge = cross_count > leg_count - legs_for_stab;
-            const bool reach = ch.parent_valid || (reach_count >= legs_for_stab);
-            mine |= (reach ? 1u : 0u) | ((reach && !edge) ? 2u : 0u) | (edge ? 4u : 0u);
-        }
+        mine |= oct_item_flags<kFast>(ch, vect, h2, hd, legs, spheres, leg_count, legs_for_stab, convex_r2);
     }
     // wave OR, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) mine |= __shfl_xor(mine, off);
@@ -162,8 +193,8 @@ template <bool kFast>
 __global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
     const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
     const float* __restrict__ fy, const float* __restrict__ fz, size_t nf, const float* __restrict__ boxes, size_t ntiles,
-    const LrmCompiledLeg* __restrict__ legs, int leg_count, int legs_for_stab, float reach_len, float convex_r2,
-    uint32_t* __restrict__ flags) {
+    const LrmCompiledLeg* __restrict__ legs, const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float reach_len,
+    float convex_r2, uint32_t* __restrict__ flags) {
     __shared__ uint32_t s_flags, s_ntiles, s_nchunks;
     __shared__ uint32_t s_tiles[kOctBlock];
     __shared__ uint32_t s_chunks[kOctMaxChunks];
@@ -172,6 +203,7 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
         if (ch.skip) continue; // block-uniform
         const float H[3] = {fabsf(ch.ph[0] + reach_len), fabsf(ch.ph[1] + reach_len), fabsf(ch.ph[2] + reach_len)};
         const float h2 = ch.h[0] * ch.h[0] + ch.h[1] * ch.h[1] + ch.h[2] * ch.h[2];
+        const float hd = sqrtf(h2 + fmaxf(ch.margin, 0.f)) * 1.0001f + 0.01f;
         if (threadIdx.x == 0) s_flags = 0;
         __syncthreads();
         for (size_t tile0 = 0; tile0 < ntiles; tile0 += kOctBlock) {
@@ -195,24 +227,7 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
                 if (f < nf) {
                     const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
                     if (in_box(vect, ch.ph[0] + reach_len, ch.ph[1] + reach_len, ch.ph[2] + reach_len)) {
-                        for (int a = 0; a < ch.n_angles; a++) {
-                            int reach_count = 0, cross_count = 0;
-                            for (int l = 0; l < leg_count; l++) {
-                                const LrmCompiledLeg& L = legs[a * leg_count + l];
-                                LrmVec3 v = vect;
-                                bool sub;
-                                if (kFast) sub = lrm_dist_global_filtered(L, LrmDistTables{&L.lists[0][0], &L.dist_tab[0][0], &L.corner_tab[0]}, v);
-                                else sub = lrm_dist_global(L, &L.lists[0][0], v);
-                                bool cross;
-                                if (h2 > convex_r2) cross = in_box(v, ch.h[0], ch.h[1], ch.h[2]);
-                                else cross = (v.x * v.x + v.y * v.y + v.z * v.z) < h2 + ch.margin;
-                                cross_count += cross;
-                                reach_count += sub;
-                            }
-                            const bool edge = cross_count > leg_count - legs_for_stab;
-                            const bool reach = ch.parent_valid || (reach_count >= legs_for_stab);
-                            mine |= (reach ? 1u : 0u) | ((reach && !edge) ? 2u : 0u) | (edge ? 4u : 0u);
-                        }
+                        mine = oct_item_flags<kFast>(ch, vect, h2, hd, legs, spheres, leg_count, legs_for_stab, convex_r2);
                     }
                 }
                 for (int off = 32; off > 0; off >>= 1) mine |= __shfl_xor(mine, off);
@@ -224,6 +239,57 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
         if (threadIdx.x == 0) flags[child] = s_flags;
         __syncthreads();
     }
+}
+
+// ---- Morton order on the device ----------------------------------------------------------------------
+// The chunk-culled kernel wants consecutive footholds to be neighbours in space.  (The first version sorted on the
+// host: 0.35 s of the 0.44 s a 4e6-foothold call took.)  Keys as lrm_morton_order: 10 bits per axis of the cloud's
+// bounding box, interleaved; hipcub radix sort of (key, index); gather.  The flags are ORs over footholds, so the
+// order -- and the order among equal keys -- changes no result.
+__global__ __launch_bounds__(kOctBlock) void oct_aos_to_soa_kernel(const float* __restrict__ aos, size_t nf, float* __restrict__ x,
+                                                                  float* __restrict__ y, float* __restrict__ z) {
+    const size_t i = (size_t)blockIdx.x * kOctBlock + threadIdx.x;
+    if (i >= nf) return;
+    x[i] = aos[3 * i];
+    y[i] = aos[3 * i + 1];
+    z[i] = aos[3 * i + 2];
+}
+struct OctBounds {
+    float lo[3], inv[3]; // inv = 1 / span, 0 for a flat axis
+};
+__device__ __forceinline__ uint32_t oct_spread10(uint32_t v) { // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(kOctBlock) void oct_keys_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ z, size_t nf, OctBounds b,
+                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const size_t i = (size_t)blockIdx.x * kOctBlock + threadIdx.x;
+    if (i >= nf) return;
+    const float p[3] = {x[i], y[i], z[i]};
+    uint32_t k = 0;
+    for (int a = 0; a < 3; a++) {
+        float t = (p[a] - b.lo[a]) * b.inv[a];
+        if (!(t >= 0.f)) t = 0.f; // nan / below
+        if (t > 1.f) t = 1.f;
+        k |= oct_spread10((uint32_t)(t * 1023.f)) << a;
+    }
+    keys[i] = k;
+    idx[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(kOctBlock) void oct_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ z, const uint32_t* __restrict__ idx, size_t nf,
+                                                              float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz) {
+    const size_t i = (size_t)blockIdx.x * kOctBlock + threadIdx.x;
+    if (i >= nf) return;
+    const uint32_t j = idx[i];
+    sx[i] = x[j];
+    sy[i] = y[j];
+    sz[i] = z[j];
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -324,19 +390,37 @@ void lrm_octree_default_settings(LrmOctreeSettings* s) {
 const char* lrm_octree_last_error(void) { return g_oct_err.c_str(); }
 
 // apply_oct, several_leg_octree.cu:391-488
+static int apply_oct_impl(const float* footholds, const float* dev_x, const float* dev_y, const float* dev_z, size_t nf,
+                          const LrmLegDimensions* dim, const LrmOctreeSettings* st_in, float* centers_out, size_t capacity,
+                          size_t* n_out, float* ms, int rank, int world, LrmOctExchange exchange, void* user);
+
 int lrm_apply_oct(const float* footholds, size_t nf, const LrmLegDimensions* dim, const LrmOctreeSettings* st_in,
                   float* centers_out, size_t capacity, size_t* n_out, float* ms) {
     return lrm_apply_oct_sharded(footholds, nf, dim, st_in, centers_out, capacity, n_out, ms, 0, 1, nullptr, nullptr);
+}
+int lrm_apply_oct_sharded(const float* footholds, size_t nf, const LrmLegDimensions* dim, const LrmOctreeSettings* st_in,
+                          float* centers_out, size_t capacity, size_t* n_out, float* ms, int rank, int world,
+                          LrmOctExchange exchange, void* user) {
+    if (nf && !footholds) { g_oct_err = "null argument"; return LRM_EINVAL; }
+    return apply_oct_impl(footholds, nullptr, nullptr, nullptr, nf, dim, st_in, centers_out, capacity, n_out, ms, rank, world, exchange, user);
+}
+int lrm_apply_oct_dev(const float* fx, const float* fy, const float* fz, size_t nf, const LrmLegDimensions* dim,
+                      const LrmOctreeSettings* st_in, float* centers_out, size_t capacity, size_t* n_out, float* ms, int rank,
+                      int world, LrmOctExchange exchange, void* user) {
+    if (nf && !(fx && fy && fz)) { g_oct_err = "null argument"; return LRM_EINVAL; }
+    return apply_oct_impl(nullptr, fx, fy, fz, nf, dim, st_in, centers_out, capacity, n_out, ms, rank, world, exchange, user);
 }
 
 // The same tree on `world` GPUs (one process each): the children of every level are dealt round-robin to the ranks,
 // each rank evaluates its share, and `exchange` combines the flag words (element-wise maximum: every child has exactly
 // one owner, the others contribute 0).  Every rank builds the identical tree and returns all valid leaves.
-int lrm_apply_oct_sharded(const float* footholds, size_t nf, const LrmLegDimensions* dim, const LrmOctreeSettings* st_in,
+static int apply_oct_impl(const float* footholds /* host AoS, or null */, const float* dev_x, const float* dev_y, const float* dev_z,
+                          size_t nf, const LrmLegDimensions* dim, const LrmOctreeSettings* st_in,
                           float* centers_out, size_t capacity, size_t* n_out, float* ms, int rank, int world,
                           LrmOctExchange exchange, void* user) {
     auto fail = [](int code, const char* w) { g_oct_err = w; return code; };
-    if (!dim || !n_out || (nf && !footholds) || (capacity && !centers_out)) return fail(LRM_EINVAL, "null argument");
+    if (!dim || !n_out || (nf && !footholds && !(dev_x && dev_y && dev_z)) || (capacity && !centers_out)) return fail(LRM_EINVAL, "null argument");
+    if (nf >= ((size_t)1 << 31)) return fail(LRM_EINVAL, "more than 2^31 - 1 footholds: shard the cloud");
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !exchange)) return fail(LRM_EINVAL, "bad rank / world / exchange");
     LrmOctreeSettings st;
     if (st_in) st = *st_in;
@@ -355,7 +439,10 @@ int lrm_apply_oct_sharded(const float* footholds, size_t nf, const LrmLegDimensi
             return (e_ == hipErrorOutOfMemory) ? LRM_ENOMEM : LRM_ENODEV;      \
         }                                                                      \
     } while (0)
-    float *d_f = nullptr, *d_boxes = nullptr;
+    float *d_f = nullptr, *d_boxes = nullptr, *d_tmp_aos = nullptr, *d_tmp_soa = nullptr;
+    uint32_t* d_keys = nullptr;
+    void* d_sort_tmp = nullptr;
+    float4* d_spheres = nullptr;
     LrmCompiledLeg* d_legs = nullptr;
     OctChild* d_children = nullptr;
     uint32_t* d_flags = nullptr;
@@ -364,35 +451,79 @@ int lrm_apply_oct_sharded(const float* footholds, size_t nf, const LrmLegDimensi
     auto cleanup = [&]() {
         if (d_f) (void)hipFree(d_f);
         if (d_boxes) (void)hipFree(d_boxes);
+        if (d_tmp_aos) (void)hipFree(d_tmp_aos);
+        if (d_tmp_soa) (void)hipFree(d_tmp_soa);
+        if (d_keys) (void)hipFree(d_keys);
+        if (d_sort_tmp) (void)hipFree(d_sort_tmp);
         if (d_legs) (void)hipFree(d_legs);
+        if (d_spheres) (void)hipFree(d_spheres);
         if (d_children) (void)hipFree(d_children);
         if (d_flags) (void)hipFree(d_flags);
         if (ev_a) (void)hipEventDestroy(ev_a);
         if (ev_b) (void)hipEventDestroy(ev_b);
     };
 
+    const bool dbg = getenv("LRM_OCT_DEBUG") != nullptr; // host-side phase times on stderr
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t_phase = now();
     // footholds as SoA on the device, in Morton order (the flags are ORs over footholds: the order changes nothing,
     // but consecutive footholds then fill compact boxes for oct_validity_chunked_kernel)
-    std::vector<float> soa(3 * (nf ? nf : 1));
-    {
-        std::vector<size_t> order;
-        lrm_host_morton_order(footholds, nf, &order);
-        for (size_t k = 0; k < nf; k++) {
-            const size_t i = order[k];
-            soa[k] = footholds[3 * i];
-            soa[nf + k] = footholds[3 * i + 1];
-            soa[2 * nf + k] = footholds[3 * i + 2];
-        }
-    }
-    OCT_TRY(hipMalloc(&d_f, soa.size() * sizeof(float)), "hipMalloc gpu_in.elements");
-    OCT_TRY(hipMemcpy(d_f, soa.data(), soa.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy gpu_in.elements");
     const size_t ntiles = (nf + 1023) / 1024;
+    OCT_TRY(hipMalloc(&d_f, 3 * (nf ? nf : 1) * sizeof(float)), "hipMalloc gpu_in.elements");
+    if (nf) {
+        const unsigned pb = (unsigned)((nf + kOctBlock - 1) / kOctBlock);
+        const float *ux = dev_x, *uy = dev_y, *uz = dev_z;
+        if (footholds) { // host AoS (the reference's Array<float3>): upload, split
+            OCT_TRY(hipMalloc(&d_tmp_aos, 3 * nf * sizeof(float)), "hipMalloc footholds");
+            OCT_TRY(hipMalloc(&d_tmp_soa, 3 * nf * sizeof(float)), "hipMalloc footholds");
+            OCT_TRY(hipMemcpy(d_tmp_aos, footholds, 3 * nf * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy gpu_in.elements");
+            hipLaunchKernelGGL(oct_aos_to_soa_kernel, dim3(pb), dim3(kOctBlock), 0, nullptr, d_tmp_aos, nf, d_tmp_soa, d_tmp_soa + nf, d_tmp_soa + 2 * nf);
+            OCT_TRY(hipGetLastError(), "Kernel launch");
+            ux = d_tmp_soa;
+            uy = d_tmp_soa + nf;
+            uz = d_tmp_soa + 2 * nf;
+        }
+        // bounding box of the cloud: the tile boxes of the unsorted cloud, reduced on the host
+        OCT_TRY(hipMalloc(&d_boxes, ntiles * 17 * 6 * sizeof(float)), "hipMalloc foothold boxes");
+        hipLaunchKernelGGL(oct_boxes_kernel, dim3((unsigned)ntiles), dim3(kOctBlock), 0, nullptr, ux, uy, uz, nf, ntiles, d_boxes);
+        OCT_TRY(hipGetLastError(), "Kernel launch");
+        std::vector<float> tb(ntiles * 6);
+        OCT_TRY(hipMemcpy(tb.data(), d_boxes, tb.size() * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy boxes");
+        OctBounds ob;
+        for (int a = 0; a < 3; a++) {
+            float lo = 3.0e38f, hi = -3.0e38f;
+            for (size_t t = 0; t < ntiles; t++) {
+                lo = std::min(lo, tb[t * 6 + a]);
+                hi = std::max(hi, tb[t * 6 + 3 + a]);
+            }
+            ob.lo[a] = lo;
+            ob.inv[a] = (hi > lo && std::isfinite(hi - lo)) ? 1.0f / (hi - lo) : 0.f;
+        }
+        OCT_TRY(hipMalloc(&d_keys, 4 * nf * sizeof(uint32_t)), "hipMalloc sort keys"); // keys, indices, and their sorted copies
+        uint32_t *k_in = d_keys, *i_in = d_keys + nf, *k_out = d_keys + 2 * nf, *i_out = d_keys + 3 * nf;
+        hipLaunchKernelGGL(oct_keys_kernel, dim3(pb), dim3(kOctBlock), 0, nullptr, ux, uy, uz, nf, ob, k_in, i_in);
+        OCT_TRY(hipGetLastError(), "Kernel launch");
+        size_t sort_bytes = 0;
+        OCT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k_in, k_out, i_in, i_out, (int)nf, 0, 30, (hipStream_t) nullptr), "radix sort (size)");
+        OCT_TRY(hipMalloc(&d_sort_tmp, sort_bytes ? sort_bytes : 16), "hipMalloc sort workspace");
+        OCT_TRY(hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, sort_bytes, k_in, k_out, i_in, i_out, (int)nf, 0, 30, (hipStream_t) nullptr), "radix sort");
+        hipLaunchKernelGGL(oct_gather_kernel, dim3(pb), dim3(kOctBlock), 0, nullptr, ux, uy, uz, i_out, nf, d_f, d_f + nf, d_f + 2 * nf);
+        OCT_TRY(hipGetLastError(), "Kernel launch");
+        OCT_TRY(hipDeviceSynchronize(), "footholds in Morton order");
+        (void)hipFree(d_sort_tmp); d_sort_tmp = nullptr;
+        (void)hipFree(d_keys); d_keys = nullptr;
+        if (d_tmp_aos) { (void)hipFree(d_tmp_aos); d_tmp_aos = nullptr; }
+        if (d_tmp_soa) { (void)hipFree(d_tmp_soa); d_tmp_soa = nullptr; }
+        (void)hipFree(d_boxes); d_boxes = nullptr;
+    }
     if (nf) {
         OCT_TRY(hipMalloc(&d_boxes, ntiles * 17 * 6 * sizeof(float)), "hipMalloc foothold boxes");
         hipLaunchKernelGGL(oct_boxes_kernel, dim3((unsigned)ntiles), dim3(kOctBlock), 0, nullptr, d_f, d_f + nf, d_f + 2 * nf, nf, ntiles, d_boxes);
         OCT_TRY(hipGetLastError(), "Kernel launch");
     }
 
+    if (dbg) { (void)hipDeviceSynchronize(); fprintf(stderr, "apply_oct: %zu footholds ordered on the device in %.2f ms\n", nf, ms_since(t_phase)); t_phase = now(); }
     // compiled legs for every (orientation sample, mounted leg)
     const int n_angles_max = st.angle_sample[0] * st.angle_sample[1] * st.angle_sample[2];
     std::vector<LrmCompiledLeg> legs((size_t)n_angles_max * st.leg_count);
@@ -410,9 +541,22 @@ int lrm_apply_oct_sharded(const float* footholds, size_t nf, const LrmLegDimensi
     const bool fast = all_fast && lrm_get_mode() != LRM_MODE_STRICT;
     OCT_TRY(hipMalloc(&d_legs, legs.size() * sizeof(LrmCompiledLeg)), "hipMalloc legs");
     OCT_TRY(hipMemcpy(d_legs, legs.data(), legs.size() * sizeof(LrmCompiledLeg), hipMemcpyHostToDevice), "hipMemcpy legs");
+    // bounding sphere of what each (orientation, leg) reaches, in the frame distance_global takes its point in:
+    // pair_center lives in the frame of reachable_rotate_leg (the target relative to the body, before the quaternion);
+    // distance_global first applies qtRotate(qtInvert(q), .), so the centre goes through qtRotate(q, .)
+    std::vector<float4> spheres(legs.size());
+    const bool no_cull = getenv("LRM_OCT_NOCULL") && getenv("LRM_OCT_NOCULL")[0] == '1'; // tests: every work item evaluated
+    for (size_t k = 0; k < legs.size(); k++) {
+        const LrmCompiledLeg& L = legs[k];
+        const LrmVec3 c = lrm_qrot(L.fwd_rot, LrmVec3{L.pair_center[0], L.pair_center[1], L.pair_center[2]});
+        spheres[k] = make_float4(c.x, c.y, c.z, no_cull ? 1.0e18f : std::sqrt(L.pair_r2) * 1.0001f + 0.5f);
+    }
+    OCT_TRY(hipMalloc(&d_spheres, spheres.size() * sizeof(float4)), "hipMalloc spheres");
+    OCT_TRY(hipMemcpy(d_spheres, spheres.data(), spheres.size() * sizeof(float4), hipMemcpyHostToDevice), "hipMemcpy spheres");
     OCT_TRY(hipEventCreate(&ev_a), "hipEventCreate");
     OCT_TRY(hipEventCreate(&ev_b), "hipEventCreate");
 
+    if (dbg) { fprintf(stderr, "apply_oct: %zu legs compiled and uploaded in %.2f ms\n", legs.size(), ms_since(t_phase)); t_phase = now(); }
     std::vector<Node> nodes(1);
     for (int i = 0; i < 3; i++) {
         nodes[0].c[i] = st.box_center[i];
@@ -485,15 +629,17 @@ int lrm_apply_oct_sharded(const float* footholds, size_t nf, const LrmLegDimensi
             const float cr2 = st.convex_radius * st.convex_radius;
             // LRM_OCT_BRUTE=1 (tests): every level with the every-foothold kernel, for comparison
             const bool brute = getenv("LRM_OCT_BRUTE") && getenv("LRM_OCT_BRUTE")[0] == '1' && nc <= 65535;
-            if (nc >= (size_t)kOctChunkedFrom && !brute) {
+            size_t chunked_from = (size_t)kOctChunkedFrom;
+            if (const char* e = getenv("LRM_OCT_CHUNKED_FROM")) chunked_from = (size_t)atol(e); // experiments
+            if (nc >= chunked_from && !brute) {
                 // many small children: one workgroup per child, only the footholds of nearby chunks
                 const dim3 grid((unsigned)std::min<size_t>(nc, (size_t)256 * 64));
                 if (fast)
                     hipLaunchKernelGGL(oct_validity_chunked_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
                 else
                     hipLaunchKernelGGL(oct_validity_chunked_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
             } else {
                 // few, huge children (the first levels): every foothold, spread over the chip; grid.y = children < 65
                 size_t gx = (nf + kOctBlock - 1) / kOctBlock;
@@ -501,10 +647,10 @@ int lrm_apply_oct_sharded(const float* footholds, size_t nf, const LrmLegDimensi
                 const dim3 grid((unsigned)gx, (unsigned)nc);
                 if (fast)
                     hipLaunchKernelGGL(oct_validity_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_legs, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+                                       d_f + 2 * nf, nf, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
                 else
                     hipLaunchKernelGGL(oct_validity_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_legs, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+                                       d_f + 2 * nf, nf, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
             }
             OCT_TRY(hipGetLastError(), "Kernel launch");
             OCT_TRY(hipEventRecord(ev_b, nullptr), "hipEventRecord");
@@ -513,6 +659,7 @@ int lrm_apply_oct_sharded(const float* footholds, size_t nf, const LrmLegDimensi
             OCT_TRY(hipEventElapsedTime(&e, ev_a, ev_b), "hipEventElapsedTime");
             total_ms += e;
         }
+        if (dbg) { fprintf(stderr, "apply_oct: level %d, %zu children: %.2f ms (host + kernel)\n", depth, nc, ms_since(t_phase)); t_phase = now(); }
         if (world > 1) exchange(flags.data(), nc, user);
         // several_leg_octree.cu:134-150, with global ORs
         std::vector<int> next;
@@ -559,7 +706,9 @@ int lrm_apply_oct_sharded(const float* footholds, size_t nf, const LrmLegDimensi
     }
     *n_out = count;
     if (ms) *ms = total_ms;
+    if (dbg) { fprintf(stderr, "apply_oct: %zu nodes, leaves extracted in %.2f ms\n", nodes.size(), ms_since(t_phase)); t_phase = now(); }
     cleanup();
+    if (dbg) fprintf(stderr, "apply_oct: device memory released in %.2f ms\n", ms_since(t_phase));
 #undef OCT_TRY
     if (count > capacity) return fail(LRM_EINVAL, "output capacity too small (n_out holds the required count)");
     return LRM_OK;

@@ -164,3 +164,13 @@ def any_in_cylinder(cx, cy, cz, tx, ty, tz, radius, plus_z, minus_z, out=None):
         _capi.check(_capi.load().lrm_any_in_cylinder_dev(_dp(cx), _dp(cy), _dp(cz), nc, _dp(tx), _dp(ty), _dp(tz), nt,
                                                          radius, plus_z, minus_z, _dp(out), _stream(cx)))
     return out
+
+
+def apply_oct(x, y, z, leg, settings=None, rank=0, world=1, exchange=None):
+    """apply_oct on footholds that already live on the device (three float32 tensors); the level loop synchronises the
+    device, so this is not a stream-ordered call.  -> (centres float32[k, 3] on the host, kernel milliseconds)"""
+    torch = _torch()
+    n = _check_f32(x, y, z)
+    with torch.cuda.device(x.device):
+        torch.cuda.synchronize(x.device)  # the library works on the null stream
+        return _capi.apply_oct_dev(_dp(x), _dp(y), _dp(z), n, leg, settings, rank, world, exchange)

@@ -236,11 +236,14 @@ def apply_oct_sharded(footholds, leg, settings=None, group=None):
     """apply_oct (lrm_apply_oct) with the children of every octree level dealt round-robin to the ranks: each rank
     evaluates its share on its GPU, the per-child flag words are combined with all_reduce(MAX) once per level (every
     child has one owner, the others contribute 0), and every rank returns all valid leaves.  Each rank holds all
-    footholds.  -> (centres float32[k, 3], this rank's kernel milliseconds)"""
+    footholds, as a host array (n, 3) or as three CUDA tensors (x, y, z).  -> (centres float32[k, 3], this rank's kernel milliseconds)"""
     import torch
-    from . import _capi
+    from . import _capi, device
     dist, world, rank = _dist_info(group)
+    on_device = isinstance(footholds, (tuple, list)) and len(footholds) == 3 and all(hasattr(t, "is_cuda") and t.is_cuda for t in footholds)
     if dist is None or world == 1:
+        if on_device:
+            return device.apply_oct(footholds[0], footholds[1], footholds[2], leg, settings)
         return _capi.apply_oct(footholds, leg, settings)
     dev = _comm_device(dist, group)
 
@@ -249,4 +252,6 @@ def apply_oct_sharded(footholds, leg, settings=None, group=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         flags[:] = t.cpu().numpy().astype(np.uint32)
 
+    if on_device:  # (x, y, z) CUDA tensors: no host copy of the cloud
+        return device.apply_oct(footholds[0], footholds[1], footholds[2], leg, settings, rank, world, exchange)
     return _capi.apply_oct_sharded(footholds, leg, settings, rank, world, exchange)

@@ -27,8 +27,37 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--footholds", type=int, default=2000)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--scale", type=int, default=0,
+                    help="config-5 shape instead: this many footholds of a 10 m x 10 m relief, the reference's settings "
+                         "(root box +-5000 mm, min box 100 mm, 27 orientations below 50 mm) at --depth")
+    ap.add_argument("--depth", type=int, default=6)
     args = ap.parse_args()
     dim = lrm.get_M2_leg(0.0)
+    if args.scale:
+        rng = np.random.default_rng(5)
+        n = args.scale
+        xy = rng.uniform(-5000, 5000, (n, 2)).astype(np.float32)
+        z = (400 * np.sin(xy[:, 0] / 900) * np.cos(xy[:, 1] / 700) + 60 * np.sin(xy[:, 0] / 130) + rng.normal(0, 5, n) - 200).astype(np.float32)
+        f = np.column_stack([xy, z]).astype(np.float32)
+        st = lrm.octree_default_settings()
+        st.max_depth = args.depth
+        st.leg_number_for_stab = 3
+        t0 = time.perf_counter()
+        out, ms = lrm.apply_oct(f, dim, st)
+        wall = time.perf_counter() - t0
+        print(json.dumps({"workload": f"apply_oct, config-5 shape: {n} footholds on a 10 m x 10 m relief, depth {args.depth}, 4 legs, stability 3",
+                          "leaves": len(out), "wall_s_first_call": wall, "kernel_ms": ms}), flush=True)
+        t0 = time.perf_counter()
+        out, ms = lrm.apply_oct(f, dim, st)
+        print(json.dumps({"second_call_wall_s": time.perf_counter() - t0, "kernel_ms": ms, "leaves": len(out)}), flush=True)
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(f.T)).cuda()
+        lrm.device.apply_oct(t[0], t[1], t[2], dim, st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out, ms = lrm.device.apply_oct(t[0], t[1], t[2], dim, st)
+        print(json.dumps({"device_resident_footholds_wall_s": time.perf_counter() - t0, "kernel_ms": ms, "leaves": len(out)}), flush=True)
+        return
     cases = [
         ("two legs, 0.8 m root, depth 6", dict(half=400.0, depth=6, stab=2, legs=2, mounts=(0.0, 0.3))),
         ("four legs, stability 3, 0.8 m root, depth 5", dict(half=400.0, depth=5, stab=3, legs=4, mounts=None)),

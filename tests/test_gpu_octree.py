@@ -110,9 +110,21 @@ def test_apply_oct_at_scale_chunked_equals_every_foothold_kernel(lrm, oracle, mo
     finally:
         del os.environ["LRM_OCT_BRUTE"]
     assert len(got) > 50 and np.array_equal(got.view(np.uint32), brute.view(np.uint32))
+    # the bounding-sphere cull in front of the distance evaluations (oct_item_flags) is exact: same leaves without it
+    os.environ["LRM_OCT_NOCULL"] = "1"
+    try:
+        nocull, ms_nocull = lrm.apply_oct(f, dim, st)
+    finally:
+        del os.environ["LRM_OCT_NOCULL"]
+    assert np.array_equal(got.view(np.uint32), nocull.view(np.uint32))
+    # footholds already on the device (lrm_apply_oct_dev): the same tree
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(f.T)).cuda()
+    dev, ms_dev = lrm.device.apply_oct(t[0], t[1], t[2], dim, st)
+    assert np.array_equal(got.view(np.uint32), dev.view(np.uint32))
     shuffled, _ = lrm.apply_oct(f[rng.permutation(n)], dim, st)
     assert np.array_equal(got.view(np.uint32), shuffled.view(np.uint32))
-    print(f"apply_oct, 1e6 footholds, depth 5: {len(got)} valid leaves; chunk-culled {ms:.2f} ms of kernels, every-foothold {ms_brute:.2f} ms")
+    print(f"apply_oct, 1e6 footholds, depth 5: {len(got)} valid leaves; chunk-culled {ms:.2f} ms of kernels, every-foothold {ms_brute:.2f} ms, without the sphere cull {ms_nocull:.2f} ms")
 
 
 def _oct_worker(rank, world, port, ret):
