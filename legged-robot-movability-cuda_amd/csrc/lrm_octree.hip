@@ -137,13 +137,13 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_kernel(
 // ---- scale: footholds binned by bounding boxes --------------------------------------------------------
 // oct_validity_kernel above walks EVERY foothold for every child: fine for the few, huge boxes of the first levels
 // (its grid spreads the footholds of one child over the chip), hopeless deeper down, where a level has thousands
-// of small children that each see a handful of footholds.  From kOctChunkedFrom children on, a level runs
+// of small children that each see a handful of footholds.  From kOctChunkedFrom children on (every level but the first), a level runs
 // oct_validity_chunked_kernel instead: the footholds are in Morton order (sorted once per call), two levels of
 // axis-aligned boxes cover them in memory order (one per 1024-foothold tile, one per 64-foothold chunk, built once
 // per call by oct_boxes_kernel), and a workgroup = one child tests tile boxes, then the chunk boxes of the
 // surviving tiles, against the child's elongated box (several_leg_octree.cu:76-82) and evaluates only the
 // footholds of surviving chunks.  A child whose three flags are all set stops at once (they are ORs).
-constexpr int kOctChunkedFrom = 65;
+constexpr int kOctChunkedFrom = 9; // 1.25e7 footholds, depth 6: thresholds 1 / 9 / 65 / 257 -> 198 / 188 / 193 / 226 ms of kernels
 constexpr int kOctMaxChunks = 4096; // surviving chunks per round of 256 tiles
 
 __global__ __launch_bounds__(kOctBlock) void oct_boxes_kernel(const float* __restrict__ fx, const float* __restrict__ fy,
@@ -194,11 +194,16 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
     const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
     const float* __restrict__ fy, const float* __restrict__ fz, size_t nf, const float* __restrict__ boxes, size_t ntiles,
     const LrmCompiledLeg* __restrict__ legs, const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float reach_len,
-    float convex_r2, uint32_t* __restrict__ flags) {
+    float convex_r2, uint32_t* __restrict__ flags /* zeroed by the host */, uint32_t splits) {
     __shared__ uint32_t s_flags, s_ntiles, s_nchunks;
     __shared__ uint32_t s_tiles[kOctBlock];
     __shared__ uint32_t s_chunks[kOctMaxChunks];
-    for (size_t child = blockIdx.x; child < (size_t)n_children; child += gridDim.x) {
+    // A level with few, large children would leave most of the chip idle at one workgroup per child: `splits` workgroups
+    // share a child, each takes every splits-th round of 256 tiles, and the flags meet in the child's global word
+    // (atomicOr; read back every round for the early exit).
+    for (size_t w = blockIdx.x; w < (size_t)n_children * splits; w += gridDim.x) {
+        const size_t child = w / splits;
+        const uint32_t sp = (uint32_t)(w % splits);
         const OctChild ch = children[child];
         if (ch.skip) continue; // block-uniform
         const float H[3] = {fabsf(ch.ph[0] + reach_len), fabsf(ch.ph[1] + reach_len), fabsf(ch.ph[2] + reach_len)};
@@ -206,8 +211,17 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
         const float hd = sqrtf(h2 + fmaxf(ch.margin, 0.f)) * 1.0001f + 0.01f;
         if (threadIdx.x == 0) s_flags = 0;
         __syncthreads();
-        for (size_t tile0 = 0; tile0 < ntiles; tile0 += kOctBlock) {
-            if (threadIdx.x == 0) { s_ntiles = 0; s_nchunks = 0; }
+        for (size_t tile0 = (size_t)sp * kOctBlock; tile0 < ntiles; tile0 += (size_t)splits * kOctBlock) {
+            if (threadIdx.x == 0) {
+                s_ntiles = 0;
+                s_nchunks = 0;
+                if (splits > 1) { // what the other workgroups of this child have found, and ours to them
+                    const uint32_t mine_so_far = s_flags;
+                    const uint32_t seen = *reinterpret_cast<volatile uint32_t*>(&flags[child]);
+                    if (mine_so_far & ~seen) atomicOr(&flags[child], mine_so_far);
+                    s_flags = mine_so_far | seen;
+                }
+            }
             __syncthreads();
             if (s_flags == 7u) break; // nothing left to learn (block-uniform: read after the barrier)
             const size_t t = tile0 + threadIdx.x;
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
             __syncthreads();
         }
         __syncthreads();
-        if (threadIdx.x == 0) flags[child] = s_flags;
+        if (threadIdx.x == 0 && s_flags) atomicOr(&flags[child], s_flags);
         __syncthreads();
     }
 }
@@ -633,13 +647,17 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
             if (const char* e = getenv("LRM_OCT_CHUNKED_FROM")) chunked_from = (size_t)atol(e); // experiments
             if (nc >= chunked_from && !brute) {
                 // many small children: one workgroup per child, only the footholds of nearby chunks
-                const dim3 grid((unsigned)std::min<size_t>(nc, (size_t)256 * 64));
+                // workgroups per child: at least ~4096 workgroups in flight, at most one per round of 256 tiles
+                size_t splits = nc >= 4096 ? 1 : (4096 + nc - 1) / nc;
+                splits = std::min(splits, std::max<size_t>(1, (ntiles + kOctBlock - 1) / kOctBlock));
+                splits = std::min<size_t>(splits, 64);
+                const dim3 grid((unsigned)std::min<size_t>(nc * splits, (size_t)256 * 64));
                 if (fast)
                     hipLaunchKernelGGL(oct_validity_chunked_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits);
                 else
                     hipLaunchKernelGGL(oct_validity_chunked_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits);
             } else {
                 // few, huge children (the first levels): every foothold, spread over the chip; grid.y = children < 65
                 size_t gx = (nf + kOctBlock - 1) / kOctBlock;
