@@ -208,3 +208,25 @@ def test_rbdl_equivalent_baseline(lrm):
     assert ok[d > reach + 1e-3].mean() < 0.05
     inside = (d < 0.8 * reach) & (d > 0.5 * reach)
     assert ok[inside].mean() > 0.5
+
+
+def test_tolerance_kernels_keep_their_register_budget(lrm):
+    """The headline kernel is built for 8 waves/SIMD (64 VGPRs) without scratch; the build writes the compiler's
+    resource remarks next to the object (csrc/Makefile).  A change that spills shows up here, not as a slower bench."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(lrm.LIB_PATH), "csrc", "build", "lrm_tol_kernels.resource.txt")
+    if not os.path.exists(path):
+        pytest.skip("resource remarks not present (library built elsewhere)")
+    text = open(path).read()
+    blocks = re.split(r"remark: Function Name: ", text)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "dist_tol_staged_kernel" not in name:
+            continue
+        seen += 1
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
+        assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, name
+        assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 8, name
+    assert seen == 2  # kOp 1 and 2
