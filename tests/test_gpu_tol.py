@@ -209,3 +209,20 @@ print('plane table ok')
     env = dict(os.environ, LRM_TOL_PLANE_TABLE="1")
     out = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "plane table ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_tol_random_legs_orientations_and_boundary_hugging_clouds():
+    """A small instance of tools/stress_tol.py (random leg geometries and joint limits, random orientations; uniform,
+    planar, near-axis and boundary-hugging clouds): tolerance mode against the bit-exact mode on the device.  The
+    campaigns run while building (profiles/r02_stress_tol.txt): 4.9e8 evaluations, no mask difference, error <= 6.9e-6."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "legged-robot-movability-cuda_amd", "tools", "stress_tol.py"),
+                        "--legs", "8", "--points", "100000", "--seed", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["mask_mismatches"] == 0 and line["bit_word_mismatches"] == 0 and line["max_err"] <= TOL
+    assert line["tol_eligible"] >= 12  # most (leg, orientation) pairs do run the tolerance kernels
