@@ -45,6 +45,9 @@
 #ifndef LRM_TOL_SEG_CAP
 #define LRM_TOL_SEG_CAP 32
 #endif
+#ifndef LRM_TOL_PREFETCH
+#define LRM_TOL_PREFETCH 1
+#endif
 #ifndef LRM_TOL_GRID_MULT
 #define LRM_TOL_GRID_MULT 8
 #endif
@@ -203,6 +206,17 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
     __shared__ float4 s_task[kBlock]; // {u, z, band, tau} of a pending second plane evaluation
     __shared__ float4 s_res[kBlock];  // {du, dz, valid, doubt bits}
     const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
+#if LRM_TOL_PREFETCH
+    // The point of the NEXT round is loaded while this round's second-candidate stage runs, the first one in front of the
+    // table staging: the load latency leaves the critical path of the workgroup (three more VGPRs: 64, the limit of 8 waves).
+    LrmVec3 p_next{0.f, 0.f, 0.f};
+    {
+        const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x;
+        const size_t rb0 = (size_t)blockIdx.x * kBlock;
+        const uint32_t to = lrm_opaque(threadIdx.x * 4u);
+        if (i0 < n) p_next = LrmVec3{lrm_at(x + rb0, to), lrm_at(y + rb0, to), lrm_at(z + rb0, to)};
+    }
+#endif
     {
         const float* csrc = reinterpret_cast<const float*>(&L.circ[0][0]);
         const float* fsrc = reinterpret_cast<const float*>(&L.feat[0]);
@@ -227,8 +241,12 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         // scalar unit, the vector offset is a loop invariant -- no 64-bit address arithmetic on the vector unit
         const size_t rbase = (size_t)blockIdx.x * kBlock + (size_t)round * stride;
         const uint32_t toff = lrm_opaque(toff0), tid_o = lrm_opaque(threadIdx.x);
+#if LRM_TOL_PREFETCH
+        LrmVec3 p = p_next;
+#else
         LrmVec3 p{0.f, 0.f, 0.f};
         if (live) p = LrmVec3{lrm_at(x + rbase, toff), lrm_at(y + rbase, toff), lrm_at(z + rbase, toff)};
+#endif
         // ---- A: first candidate ----
         const LrmTolPoint S = lrm_tol_prologue(L, p);
         uint32_t lu = S.lu;
@@ -248,6 +266,14 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         if (threadIdx.x == 0) s_cnt[(round + 1u) & 1u] = 0; // nobody touches the other counter during this round
 #if !defined(LRM_TOL_EXP_NOBARRIER) // timing experiments only (wrong results)
         __syncthreads();
+#endif
+#if LRM_TOL_PREFETCH
+        {
+            const uint32_t i_next = i + stride;
+            const size_t rb_next = rbase + stride;
+            p_next = LrmVec3{0.f, 0.f, 0.f};
+            if (i_next < n) p_next = LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
+        }
 #endif
 #if defined(LRM_TOL_EXP_NOB)
         const uint32_t total = 0;
