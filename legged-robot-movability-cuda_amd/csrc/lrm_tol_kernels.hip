@@ -3,15 +3,17 @@
 // Two launches per call, no host synchronisation between them and NO global atomics (a first version appended
 // the doubtful points to one queue with one atomicAdd per wave: 42 000 same-address atomics per 1e7 points cost
 // 0.42 ms, five times the arithmetic):
-//   dist_tol_kernel   every point: FP32-FMA / v_rsq_f32 evaluation (no trigonometry, no IEEE sqrt / div), reach
-//                     mask + ballot bit words + distance vector; a point with any decision inside its error band
-//                     is appended to the SEGMENT of its workgroup (kSegCap slots per workgroup, slot numbers from
-//                     an LDS counter); the workgroup stores its count at the end.
+//   dist_tol_staged_kernel  every point: FP32-FMA / v_rsq_f32 evaluation (no trigonometry, no IEEE sqrt / div), reach
+//                     mask + ballot bit words + distance vector.  The more promising yaw candidate in the owning lane; the
+//                     second one only where a lower bound cannot exclude it, compacted over the workgroup through LDS.  A
+//                     point with any decision inside its error band is appended to the SEGMENT of its workgroup (kSegCap
+//                     slots per workgroup, slot numbers from an LDS counter); the workgroup stores its count at the end.
+//                     (dist_tol_kernel: the unstaged form, both candidates in the owning lane, -DLRM_TOL_STAGED=0.)
 //   tol_fixup_kernel  one wave per kSegPerWave segments: prefix sum of their counts, then the queued points
-//                     (a few 1e-3 of the cloud), 64 at a time, through the bit-exact filtered code of
-//                     LRM_MODE_FAST, overwriting their outputs.  A segment that overflowed (a cloud hugging a
-//                     decision boundary) has ALL the points of its workgroup re-evaluated: slow, never wrong.
-//                     Counts are rewritten by every call: nothing to reset.
+//                     (a few 1e-3 of the cloud), 32 at a time -- two lanes per point, one yaw candidate each -- through
+//                     the bit-exact filtered code of LRM_MODE_FAST, overwriting their outputs.  A segment that overflowed
+//                     (a cloud hugging a decision boundary) has ALL the points of its workgroup re-evaluated: slow, never
+//                     wrong.  Counts are rewritten by every call: nothing to reset.
 // Layout as lrm_kernels.hip: SoA coordinates, byte mask, ballot words, SoA distance field.  The per-leg block
 // (LrmTolLeg, 1.5 KB) travels by value in the kernarg segment; its per-lane tables are staged in LDS.
 #include <hip/hip_runtime.h>
