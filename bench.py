@@ -380,7 +380,7 @@ def main():
                             (f"BASELINE config 4: single M2 leg, reach+distance on ONE cloud of {n_total} uniform-random 3-D targets "
                              f"(chunk-seeded), sharded contiguously over {world} GPUs ({n} points on rank 0), SoA resident in HBM"),
                 "points_total": n_total, "points_per_gpu": n, "mode": args.mode,
-                "mode_contract": {"tol": "reach mask bit-exact, distance within 1e-5 of max(|d|, |p|/8) (BASELINE contract tolerance)",
+                "mode_contract": {"tol": "reach mask bit-exact, distance within 1e-5 of max(|d|, (|p| + body)/8) (BASELINE contract tolerance; tests/tolcheck.py)",
                                   "fast": "mask and every float of the distance field bit-identical to the reference's host path",
                                   "strict": "as fast, reference operation order"}[args.mode],
                 "exchange": "none" if world == 1 else f"{'RCCL' if backend == 'nccl' else backend} all-gather of the "

@@ -48,7 +48,7 @@ extern "C" {
 /* LRM_MODE_TOL:    BASELINE contract tolerance (csrc/lrm_point_tol.h): the reach mask and the distance's
  *                  validity byte stay bit-identical to LRM_MODE_STRICT; the distance VECTOR is computed with
  *                  FP32 FMA / v_rsq_f32 arithmetic (no atan2f / sincosf / IEEE sqrt) and lands on the same
- *                  boundary feature as the reference's: |d - d_ref| <= 1e-5 max(|d_ref|, |p| / 8) per point
+ *                  boundary feature as the reference's: |d - d_ref| <= 1e-5 max(|d_ref|, (|p| + body) / 8) per point
  *                  (about 10 ulp of the coordinates at most; tests/tolcheck.py).  Points with any decision inside its
  *                  error band are re-evaluated by the LRM_MODE_FAST code in a second small launch and are
  *                  bit-identical.  Applies to the distance / fused entry points; reach-only and pair kernels

@@ -59,7 +59,7 @@ def main():
             b2 = torch.empty_like(bits)
             lrm_amd.device.reach_dist(x, y, z, leg, None, mask=m2, out=f2, bits=b2)
             lrm_amd.set_mode(modes[name])
-            err = (field - f2).norm(dim=0) / torch.maximum(f2.norm(dim=0), cloud.norm(dim=0) / 8)
+            err = (field - f2).norm(dim=0) / torch.maximum(f2.norm(dim=0), (cloud.norm(dim=0) + float(leg[1])) / 8)
             out["tol_check"] = {"mask_mismatches": int((mask != m2).sum()), "bit_word_mismatches": int((bits != b2).sum()),
                                 "max_err": float(err.max()), "nonfinite": int((~torch.isfinite(field)).sum())}
             del m2, f2, b2, err

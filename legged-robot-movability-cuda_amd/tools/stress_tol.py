@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--legs", type=int, default=40)
     ap.add_argument("--points", type=int, default=400_000)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--tilt", type=float, default=1.0, help="scale of the random body rotation (1: up to ~40 degrees)")
     args = ap.parse_args()
     import torch
     import lrm_amd as lrm
@@ -54,7 +55,7 @@ def main():
             if qi == 0:
                 q = np.array([1, 0, 0, 0], np.float32)
             else:
-                q = rng.normal(size=4) * np.array([1.0, 0.25, 0.25, 0.35])
+                q = rng.normal(size=4) * np.array([1.0, 0.25 * args.tilt, 0.25 * args.tilt, 0.35 * args.tilt])
                 q[0] = abs(q[0]) + 0.8
                 q = (q / np.linalg.norm(q)).astype(np.float32)
             out["tol_eligible"] += int(lrm.dbg_tol_ok(leg, q))
@@ -63,6 +64,22 @@ def main():
                 "grid": np.column_stack([rng.uniform(-100, 601, n), np.zeros(n), rng.uniform(-350, 51, n)]).astype(np.float32),
                 "axis": (rng.normal(size=(n, 3)) * np.array([12.0, 12.0, 150.0]) + np.array([leg[1], 0, 0])).astype(np.float32),
             }
+            # around the coxa axis for THIS orientation: points chosen in the coxa frame (radius up to 60 mm from the axis,
+            # where the yaw direction amplifies every rounding by target radius / r), mapped back to the body frame:
+            # x_coxa = Rp (Rz (Rq^-1 p) - (body, 0, 0)),  Rz = rotation by -body_angle about z, Rp = by -coxa_pitch about y
+            rr = rng.uniform(0, 60, n) ** 1.0
+            th = rng.uniform(-np.pi, np.pi, n)
+            c = np.column_stack([rr * np.cos(th), rr * np.sin(th), rng.uniform(-1.1 * reach, 1.1 * reach, n)])
+            pit = float(leg[2])
+            cp, sp = np.cos(pit), np.sin(pit)  # Rp^-1: rotation by +coxa_pitch
+            v = np.column_stack([c[:, 0] * cp - c[:, 2] * sp, c[:, 1], c[:, 0] * sp + c[:, 2] * cp])
+            v[:, 0] += float(leg[1])
+            ba = float(leg[0])
+            cb, sb = np.cos(ba), np.sin(ba)    # Rz^-1: rotation by +body_angle
+            v = np.column_stack([v[:, 0] * cb - v[:, 1] * sb, v[:, 0] * sb + v[:, 1] * cb, v[:, 2]])
+            qw, qv = float(q[0]), np.asarray(q[1:], np.float64)
+            tq = 2 * np.cross(qv, v)
+            clouds["coxa_axis"] = (v + qw * tq + np.cross(qv, tq)).astype(np.float32)  # rotate by q
             # boundary cloud: uniform points moved along their own distance vector, jittered
             u = clouds["uniform"]
             t = torch.from_numpy(np.ascontiguousarray(u.T)).cuda()
@@ -74,7 +91,7 @@ def main():
                 m1, d1, b1 = run(lrm.MODE_FAST, t[0], t[1], t[2], leg, q)
                 m2, d2, b2 = run(lrm.MODE_TOL, t[0], t[1], t[2], leg, q)
                 torch.cuda.synchronize()
-                err = (d2 - d1).norm(dim=0) / torch.maximum(d1.norm(dim=0), t.norm(dim=0) / 8)
+                err = (d2 - d1).norm(dim=0) / torch.maximum(d1.norm(dim=0), (t.norm(dim=0) + float(leg[1])) / 8)
                 err = torch.nan_to_num(err, nan=0.0)  # 0 / 0 at a point on the boundary with a zero vector in both modes
                 bad_m = int((m1 != m2).sum())
                 bad_b = int((b1 != b2).sum())

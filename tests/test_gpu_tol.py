@@ -1,7 +1,7 @@
 """LRM_MODE_TOL on the GPU (run with -m gpu): the tolerance kernel + its fix-up launch, through the C ABI.
 
 Contract (include/lrm.h): reach mask, validity byte and ballot bit words BIT-IDENTICAL to the oracle; distance
-vector within the tolerance of tests/tolcheck.py (1e-5 relative to max(|d_ref|, |p| / 8)); points the kernel
+vector within the tolerance of tests/tolcheck.py (1e-5 relative to max(|d_ref|, (|p| + body) / 8)); points the kernel
 sent to its fix-up launch are bit-identical altogether."""
 import numpy as np
 import pytest
@@ -36,13 +36,13 @@ def packed(mask):
     return np.packbits(np.pad(mask, (0, (-n) % 64)), bitorder="little").view(np.uint64)
 
 
-def check_outputs(pts, m, v, d, bits, want_m, want_v, want_d):
+def check_outputs(pts, m, v, d, bits, want_m, want_v, want_d, leg):
     assert np.array_equal(m, want_m), "reach mask must be bit-exact in the tolerance mode"
     if v is not None:
         assert np.array_equal(v, want_v), "validity byte must be bit-exact in the tolerance mode"
     if bits is not None:
         assert np.array_equal(bits.view(np.uint64), packed(want_m))
-    e = field_error(pts, d, want_d)
+    e = field_error(pts, d, want_d, leg)
     assert e["metric"].max(initial=0.0) <= TOL, f"distance error {e['metric'].max():.3e}, abs {e['abs'].max():.3e} mm"
 
 
@@ -55,8 +55,8 @@ def test_tol_device_api_matches_reference_fixture(lrm, torch_cuda, name):
     m, d, bits = lrm.device.reach_dist(x, y, z, c["leg"], c["quat"], mask=torch_cuda.empty(n, dtype=torch_cuda.uint8, device="cuda"), bits=bits)
     d1, v = lrm.device.dist(x, y, z, c["leg"], c["quat"])
     torch_cuda.cuda.synchronize()
-    check_outputs(c["points"], m.cpu().numpy(), v.cpu().numpy(), d.cpu().numpy().T, bits.cpu().numpy(), c["mask"], c["valid"], c["dist"])
-    check_outputs(c["points"], m.cpu().numpy(), None, d1.cpu().numpy().T, None, c["mask"], c["valid"], c["dist"])
+    check_outputs(c["points"], m.cpu().numpy(), v.cpu().numpy(), d.cpu().numpy().T, bits.cpu().numpy(), c["mask"], c["valid"], c["dist"], c["leg"])
+    check_outputs(c["points"], m.cpu().numpy(), None, d1.cpu().numpy().T, None, c["mask"], c["valid"], c["dist"], c["leg"])
 
 
 @pytest.mark.parametrize("name", golden_cases("cube"))
@@ -76,7 +76,7 @@ def test_tol_host_soa_api(lrm, name):
     _capi.check(lrm.lib().lrm_dist_soa(_capi._ptr(xs[0]), _capi._ptr(xs[1]), _capi._ptr(xs[2]), n, _capi._ptr(leg),
                                        _capi._ptr(q), _capi._ptr(out[0]), _capi._ptr(out[1]), _capi._ptr(out[2]),
                                        _capi._ptr(valid), C.addressof(ms)))
-    check_outputs(pts, valid, valid, np.stack(out, 1), None, c["valid"], c["valid"], c["dist"])
+    check_outputs(pts, valid, valid, np.stack(out, 1), None, c["valid"], c["valid"], c["dist"], c["leg"])
 
 
 @pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 257, 4099, 100003, 1048577])
@@ -97,7 +97,7 @@ def test_tol_ragged_sizes_and_guards(lrm, oracle, torch_cuda, n):
     torch_cuda.cuda.synchronize()
     want_d, want_v = oracle.dist(pts, leg, q)
     d = np.stack([c[:n].cpu().numpy() for c in comps], 1)
-    check_outputs(pts, mask[:n].cpu().numpy(), None, d, bits[:nw].cpu().numpy(), oracle.reach(pts, leg, q), want_v, want_d)
+    check_outputs(pts, mask[:n].cpu().numpy(), None, d, bits[:nw].cpu().numpy(), oracle.reach(pts, leg, q), want_v, want_d, leg)
     assert (mask[n:] == 7).all() and (bits[nw:] == -1).all()
     assert all((c[n:] == -777.0).all() for c in comps), "kernels must not write past n"
 
@@ -111,8 +111,8 @@ def test_tol_random_cloud_1e6_legs_and_orientations(lrm, oracle, torch_cuda):
             m, d = lrm.device.reach_dist(x, y, z, leg, q)
             torch_cuda.cuda.synchronize()
             want_d, want_v = oracle.dist(pts, leg, q)
-            check_outputs(pts, m.cpu().numpy(), None, d.cpu().numpy().T, None, oracle.reach(pts, leg, q), want_v, want_d)
-            worst = max(worst, summary(pts, d.cpu().numpy().T, want_d)["max_metric"])
+            check_outputs(pts, m.cpu().numpy(), None, d.cpu().numpy().T, None, oracle.reach(pts, leg, q), want_v, want_d, leg)
+            worst = max(worst, summary(pts, d.cpu().numpy().T, want_d, leg)["max_metric"])
     print(f"tolerance mode, 9e6 evaluations: max error metric {worst:.3e} (bound {TOL:.0e})")
 
 
@@ -134,7 +134,7 @@ def test_tol_full_size_config2_1e7_points(lrm, oracle, torch_cuda):
     want_d = np.concatenate([r[1][0] for r in res])
     assert np.array_equal(m, want_m)
     assert np.array_equal(bits.view(np.uint64), packed(want_m))
-    s = summary(pts, d, want_d)
+    s = summary(pts, d, want_d, leg)
     exact = bits_equal(d, want_d).all(axis=1).mean()
     print(f"config 2, tolerance mode: {s}; {exact:.4f} of the vectors bit-identical")
     assert s["max_metric"] <= TOL
@@ -159,7 +159,7 @@ def test_tol_queue_overflow_redoes_everything(lrm, oracle, torch_cuda):
     m, d = lrm.device.reach_dist(x, y, z, leg, None)
     torch_cuda.cuda.synchronize()
     want_d, want_v = oracle.dist(pts2, leg)
-    check_outputs(pts2, m.cpu().numpy(), None, d.cpu().numpy().T, None, oracle.reach(pts2, leg), want_v, want_d)
+    check_outputs(pts2, m.cpu().numpy(), None, d.cpu().numpy().T, None, oracle.reach(pts2, leg), want_v, want_d, leg)
 
 
 def test_tol_ineligible_leg_falls_back_to_bit_exact(lrm, oracle, torch_cuda):
@@ -201,7 +201,7 @@ for leg, q in ((lrm_amd.get_M2_leg(0.0), (1, 0, 0, 0)), (lrm_amd.get_moonbot_leg
     assert np.array_equal(m.cpu().numpy(), want_m)
     packed = np.packbits(np.pad(want_m, (0, (-n) % 64)), bitorder='little').view(np.uint64)
     assert np.array_equal(bits.cpu().numpy().view(np.uint64), packed)
-    e = field_error(pts, d.cpu().numpy().T, want_d)
+    e = field_error(pts, d.cpu().numpy().T, want_d, leg)
     assert e['metric'].max() <= TOL, e['metric'].max()
 print('plane table ok')
 """

@@ -16,7 +16,7 @@ def check(lrm, pts, leg, quat, want_mask, want_valid, want_dist, max_doubt):
     sure = (doubt & 0xffff) == 0
     assert np.array_equal(m[sure], want_mask[sure]), "reach mask differs on points the filter calls certain"
     assert np.array_equal(m[sure], want_valid[sure]), "validity byte differs on points the filter calls certain"
-    e = field_error(pts[sure], d[sure], want_dist[sure])
+    e = field_error(pts[sure], d[sure], want_dist[sure], leg)
     assert e["metric"].max(initial=0.0) <= TOL, f"distance error {e['metric'].max():.3e} (abs {e['abs'].max():.3e} mm)"
     assert 1.0 - sure.mean() <= max_doubt, f"{1.0 - sure.mean():.4f} of the points are in doubt"
     return 1.0 - sure.mean()
@@ -27,10 +27,10 @@ def test_tol_matches_reference_fixture(lrm, name):
     c = load_case(name)
     if not lrm.dbg_tol_ok(c["leg"], c["quat"]):
         pytest.skip("leg not eligible for the tolerance mode (the library then uses LRM_MODE_FAST)")
-    # the planar bench grids (y = 0) contain the coxa axis (2-3 % of their points are within LRM_TOL_RMIN of it) and
+    # the planar bench grids (y = 0) contain the coxa axis (4-5 % of their points are within LRM_TOL_RMIN = 16 mm of it) and
     # lie on the symmetry plane of the symmetric legs, where the two yaw-limit planes tie exactly (3 % for the
     # moonbot leg): more doubt than a cloud
-    check(lrm, c["points"], c["leg"], c["quat"], c["mask"], c["valid"], c["dist"], 0.06)
+    check(lrm, c["points"], c["leg"], c["quat"], c["mask"], c["valid"], c["dist"], 0.09)
 
 
 @pytest.mark.parametrize("name", golden_cases("boundary") + golden_cases("special"))
@@ -78,7 +78,7 @@ def test_tol_plane_table_vs_oracle(lrm, oracle, legname, az, q):
     want_d, want_v = oracle.dist(pts, leg, q)
     sure = (doubt & 0xffff) == 0
     assert np.array_equal(m[sure], oracle.reach(pts, leg, q)[sure]) and np.array_equal(m[sure], want_v[sure])
-    e = field_error(pts[sure], d[sure], want_d[sure])
+    e = field_error(pts[sure], d[sure], want_d[sure], leg)
     assert e["metric"].max(initial=0.0) <= TOL
     assert 0 < n_fine <= 1800
     assert ((doubt & 0x100) != 0).mean() < 0.12
