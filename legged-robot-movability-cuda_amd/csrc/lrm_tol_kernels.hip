@@ -42,7 +42,7 @@
 #define LRM_TOL_STAGED 1
 #endif
 #ifndef LRM_TOL_SEG_PER_WAVE
-#define LRM_TOL_SEG_PER_WAVE 8 // ~30 queued points per fix-up wave at the usual 0.45 % of doubt: one batch
+#define LRM_TOL_SEG_PER_WAVE 4 // ~9 queued points per fix-up wave at the usual 0.37 % of doubt, 32 per pass (two lanes per point): 2 / 4 / 8 segments -> fix-up 21.7 / 15.5 / 16.8 us
 #endif
 #ifndef LRM_TOL_SEG_CAP
 #define LRM_TOL_SEG_CAP 32
