@@ -164,3 +164,44 @@ def test_apply_oct_sharded_over_two_ranks_equals_single_process(lrm):
     ret = mgr.dict()
     mp.spawn(_oct_worker, args=(2, 30500 + os.getpid() % 1000, ret), nprocs=2, join=True)
     assert ret[0] == want.tobytes() and ret[1] == want.tobytes()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_apply_oct_random_settings_three_traversals_agree(lrm, seed):
+    """Random terrains, tree sizes, leg counts, stability numbers, orientation thresholds and leg geometries: the default
+    traversal (chunk-culled kernel with several workgroups per large child + the exact bounding-sphere cull), the
+    every-foothold kernel (LRM_OCT_BRUTE=1) and the traversal without the sphere cull (LRM_OCT_NOCULL=1) must return
+    the same leaves, bit for bit, in the same order; the device-resident entry too."""
+    import os
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(20_000, 200_000))
+    half = float(rng.choice([600.0, 1200.0, 2500.0]))
+    xy = rng.uniform(-half, half, (n, 2))
+    z = (rng.uniform(20, 150) * np.sin(xy[:, 0] / rng.uniform(100, 600)) * np.cos(xy[:, 1] / rng.uniform(100, 600))
+         + rng.normal(0, 4, n) - rng.uniform(80, 260))
+    f = np.column_stack([xy, z]).astype(np.float32)
+    dim = lrm.get_M2_leg(0.0) if seed % 2 else lrm.get_moonbot_leg(0.0)
+    st = lrm.octree_default_settings()
+    for i in range(3):
+        st.box_size[i] = half
+    st.max_depth = int(rng.integers(3, 6))
+    st.leg_count = int(rng.integers(2, 5))
+    st.leg_number_for_stab = int(rng.integers(1, st.leg_count + 1))
+    for i in range(st.leg_count):
+        st.leg_mount[i] = float(rng.uniform(-np.pi, np.pi))
+    st.enable_rot_below = float(rng.choice([50.0, 200.0, 700.0]))
+    st.min_box = float(rng.choice([60.0, 100.0, 150.0]))
+    got, _ = lrm.apply_oct(f, dim, st)
+    results = {}
+    for var in ("LRM_OCT_BRUTE", "LRM_OCT_NOCULL"):
+        os.environ[var] = "1"
+        try:
+            results[var], _ = lrm.apply_oct(f, dim, st)
+        finally:
+            del os.environ[var]
+    t = torch.from_numpy(np.ascontiguousarray(f.T)).cuda()
+    results["device"], _ = lrm.device.apply_oct(t[0], t[1], t[2], dim, st)
+    for name, r in results.items():
+        assert np.array_equal(got.view(np.uint32), r.view(np.uint32)), (name, len(got), len(r))
+    print(f"seed {seed}: {n} footholds, half {half}, depth {st.max_depth}, {st.leg_count} legs, stability {st.leg_number_for_stab}: {len(got)} leaves")
