@@ -121,7 +121,7 @@ bool tol_plane_table_enabled() {
 int launch_dist_mode(int op, const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions& leg,
                      const float* quat, const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                      float* dz, void* stream) {
-    if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xff000000ull) { // 32-bit point indices in the tolerance kernels (n + one grid stride < 2^32)
+    if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xc0000000ull) { // 32-bit point indices in the tolerance kernels (n + one grid stride < 2^32)
         TolEntry& E = tol_entry(leg, quat, L);
         const LrmTolLeg& TL = E.tl;
         if (TL.tol_ok && n >= (size_t)LRM_TOLGRID_MIN_POINTS && tol_plane_table_enabled()) {
@@ -149,7 +149,7 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
         }
         if (TL.tol_ok) {
             uint32_t* w = nullptr;
-            const int rc = tol_workspace(lrm_tol_queue_words(), stream, &w);
+            const int rc = tol_workspace(lrm_tol_queue_words(n), stream, &w);
             if (rc != LRM_OK) return rc;
             HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, (hipStream_t)stream),
                     "tolerance-mode launch");

@@ -11,9 +11,9 @@ hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const flo
                                const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                                float* dz, bool fast, hipStream_t st);
 // LRM_MODE_TOL (lrm_tol_kernels.hip): the tolerance kernel + the fix-up of its doubtful points, two launches on
-// `st`.  workspace: lrm_tol_queue_words() uint32 of device memory owned by the caller for the duration of both
+// `st`.  workspace: lrm_tol_queue_words(n) uint32 of device memory owned by the caller for the duration of both
 // launches (contents are rewritten by every call; no initialisation needed).
-size_t lrm_tol_queue_words(void);
+size_t lrm_tol_queue_words(size_t n);
 hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz,
                                uint32_t* workspace, hipStream_t st);

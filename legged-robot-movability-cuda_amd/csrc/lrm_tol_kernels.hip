@@ -17,6 +17,7 @@
 // Layout as lrm_kernels.hip: SoA coordinates, byte mask, ballot words, SoA distance field.  The per-leg block
 // (LrmTolLeg, 1.5 KB) travels by value in the kernarg segment; its per-lane tables are staged in LDS.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -684,15 +685,25 @@ __global__ __launch_bounds__(kFixBlock) void tol_mid_kernel(
 
 } // namespace
 
-size_t lrm_tol_queue_words(void) { return (size_t)256 * LRM_TOL_MIN_WAVES * LRM_TOL_GRID_MULT * (kSegCap + 1); }
+// Workgroups of the main kernel for n points: every resident slot LRM_TOL_GRID_MULT times over, and for larger clouds as many
+// as keep a workgroup at about three rounds -- its doubt segment (kSegCap slots) is sized for that.  (With a fixed grid a
+// 1e8-point cloud gave each workgroup 24 rounds, most segments overflowed, and the fix-up redid whole workgroups with
+// the bit-exact code: 2.34 ms, slower than LRM_MODE_FAST.)
+static size_t tol_main_blocks(size_t n) {
+    const size_t base = (size_t)256 * LRM_TOL_MIN_WAVES * LRM_TOL_GRID_MULT;
+    const size_t need = (n + kBlock - 1) / kBlock;
+    size_t blocks = std::max(base, (need + 2) / 3);
+    if (blocks > need) blocks = need;
+    if (blocks == 0) blocks = 1;
+    return blocks;
+}
+size_t lrm_tol_queue_words(size_t n) { return tol_main_blocks(n) * (kSegCap + 1); }
 
 hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz,
-                               uint32_t* workspace /* lrm_tol_queue_words() uint32 */, hipStream_t st) {
-    const size_t cap = (size_t)256 * LRM_TOL_MIN_WAVES * LRM_TOL_GRID_MULT;
-    size_t blocks = (n + kBlock - 1) / kBlock;
-    if (blocks > cap) blocks = cap;
-    if (blocks == 0) blocks = 1;
+                               uint32_t* workspace /* lrm_tol_queue_words(n) uint32 */, hipStream_t st) {
+    const size_t blocks = tol_main_blocks(n);
+    const size_t cap = blocks;
     uint32_t* counts = workspace;
     uint32_t* queue = workspace + cap;
 #if LRM_TOL_STAGED

@@ -226,3 +226,44 @@ def test_tol_random_legs_orientations_and_boundary_hugging_clouds():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["mask_mismatches"] == 0 and line["bit_word_mismatches"] == 0 and line["max_err"] <= TOL
     assert line["tol_eligible"] >= 12  # most (leg, orientation) pairs do run the tolerance kernels
+
+
+def test_tol_large_cloud_stays_in_its_fast_regime(lrm, torch_cuda):
+    """5e7 points (one GPU's share of the 1e8-point config-4 cloud at N = 2): the main kernel's grid grows with the cloud so
+    that a workgroup's doubt segment does not overflow.  (With a fixed grid this size overflowed most segments, whole
+    workgroups were redone by the bit-exact code, and the tolerance mode was SLOWER than LRM_MODE_FAST: 2.34 against
+    2.04 ms at 1e8 points; 1.08 ms now.)  Checked here: same mask as the bit-exact mode, field inside the tolerance, and
+    clearly faster."""
+    torch = torch_cuda
+    n = 50_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42)
+    lo = torch.tensor([-200.0, -500.0, -500.0], device="cuda").view(3, 1)
+    hi = torch.tensor([700.0, 500.0, 300.0], device="cuda").view(3, 1)
+    cloud = torch.rand((3, n), device="cuda", generator=g) * (hi - lo) + lo
+    leg = lrm.get_M2_leg(0.0)
+    mask = torch.empty(n, dtype=torch.uint8, device="cuda")
+    field = torch.empty((3, n), dtype=torch.float32, device="cuda")
+    bits = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
+
+    def timed(mode, m, f, b):
+        lrm.set_mode(mode)
+        for _ in range(3):
+            lrm.device.reach_dist(cloud[0], cloud[1], cloud[2], leg, None, mask=m, out=f, bits=b)
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            lrm.device.reach_dist(cloud[0], cloud[1], cloud[2], leg, None, mask=m, out=f, bits=b)
+        e.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(e) / 10
+
+    ms_tol = timed(lrm.MODE_TOL, mask, field, bits)
+    m2, f2, b2 = torch.empty_like(mask), torch.empty_like(field), torch.empty_like(bits)
+    ms_fast = timed(lrm.MODE_FAST, m2, f2, b2)
+    lrm.set_mode(lrm.MODE_TOL)
+    assert bool((mask == m2).all()) and bool((bits == b2).all())
+    err = (field - f2).norm(dim=0) / torch.maximum(f2.norm(dim=0), (cloud.norm(dim=0) + float(leg[1])) / 8)
+    assert float(torch.nan_to_num(err, nan=0.0).max()) <= TOL
+    print(f"5e7 points: tolerance mode {ms_tol:.3f} ms, bit-exact mode {ms_fast:.3f} ms")
+    assert ms_tol < 0.75 * ms_fast
