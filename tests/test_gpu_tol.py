@@ -266,4 +266,4 @@ def test_tol_large_cloud_stays_in_its_fast_regime(lrm, torch_cuda):
     err = (field - f2).norm(dim=0) / torch.maximum(f2.norm(dim=0), (cloud.norm(dim=0) + float(leg[1])) / 8)
     assert float(torch.nan_to_num(err, nan=0.0).max()) <= TOL
     print(f"5e7 points: tolerance mode {ms_tol:.3f} ms, bit-exact mode {ms_fast:.3f} ms")
-    assert ms_tol < 0.75 * ms_fast
+    assert ms_tol < 0.85 * ms_fast  # 0.64 measured at cold clocks, 0.53 at steady clocks; 1.15 with the overflow
