@@ -285,7 +285,8 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
 #endif
         // ---- B: the compacted second plane evaluations; the lanes that take them rotate from round to round ----
         {
-            const uint32_t t = (threadIdx.x + round * 64u) & (kBlock - 1);
+            uint32_t t = threadIdx.x + (round % (uint32_t)(kBlock / 64)) * 64u; // (threadIdx.x + round * 64) mod kBlock
+            if (t >= (uint32_t)kBlock) t -= (uint32_t)kBlock;
             if (t < total) {
                 const float4 task = s_task[t];
                 float bu, bz;
