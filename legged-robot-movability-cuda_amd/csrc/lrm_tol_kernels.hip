@@ -43,10 +43,10 @@
 #define LRM_TOL_STAGED 1
 #endif
 #ifndef LRM_TOL_SEG_PER_WAVE
-#define LRM_TOL_SEG_PER_WAVE 4 // ~9 queued points per fix-up wave at the usual 0.37 % of doubt, 32 per pass (two lanes per point): 2 / 4 / 8 segments -> fix-up 21.7 / 15.5 / 16.8 us
+#define LRM_TOL_SEG_PER_WAVE 8 // segments one fix-up workgroup compacts: ~20 queued points at the usual 0.4 % of doubt, one pass of its first wave
 #endif
 #ifndef LRM_TOL_SEG_CAP
-#define LRM_TOL_SEG_CAP 32
+#define LRM_TOL_SEG_CAP 128 // doubt slots per workgroup (768 points): 17 %.  32 overflowed on the reference's planar bench grid (7 % in doubt: it contains the coxa axis and the symmetry plane)
 #endif
 #ifndef LRM_TOL_PREFETCH
 #define LRM_TOL_PREFETCH 1
@@ -74,7 +74,12 @@ extern "C" int lrm_dbg_fix_trace(uint64_t* fix_out, uint64_t* main_out) {
 namespace {
 
 constexpr int kBlock = LRM_TOL_BLOCK;
-constexpr int kFixBlock = 64;
+#ifndef LRM_TOL_FIX_BLOCK
+#define LRM_TOL_FIX_BLOCK 128 // 64 / 128 / 256 threads with 8 segments: config-2 cube 0.1158 (4 segments) / 0.1153 / 0.1174 ms per step, planar bench grid 0.3635 / 0.1292 / 0.1279
+#endif
+constexpr int kFixBlock = LRM_TOL_FIX_BLOCK; // threads of a fix-up workgroup: with the usual handful of queued points only its first wave works,
+                                             // a cloud that hugs decision boundaries (the planar bench grid: 7 % in doubt) keeps all of them busy
+constexpr int kMidBlock = 64;                // tol_mid_kernel (plane-table variant): one wave
 constexpr int kSegCap = LRM_TOL_SEG_CAP;         // doubt slots per workgroup of dist_tol_kernel
 constexpr int kSegPerWave = LRM_TOL_SEG_PER_WAVE;                 // segments one fix-up wave compacts
 
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(kGridBlock, LRM_TOLGRID_MIN_WAVES) void dist_tolgri
 
 // one wave per segment of queue A
 template <int kOp>
-__global__ __launch_bounds__(kFixBlock) void tol_mid_kernel(
+__global__ __launch_bounds__(kMidBlock) void tol_mid_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const uint32_t* __restrict__ queue_a,
@@ -654,15 +659,15 @@ __global__ __launch_bounds__(kFixBlock) void tol_mid_kernel(
     {
         const float* csrc = reinterpret_cast<const float*>(&L.circ[0][0]);
         const float* fsrc = reinterpret_cast<const float*>(&L.feat[0]);
-        for (int i = lane; i < (int)(sizeof(s_tab.circ) / 4); i += kFixBlock) reinterpret_cast<float*>(s_tab.circ)[i] = csrc[i];
-        for (int i = lane; i < (int)(sizeof(s_tab.feat) / 4); i += kFixBlock) reinterpret_cast<float*>(s_tab.feat)[i] = fsrc[i];
+        for (int i = lane; i < (int)(sizeof(s_tab.circ) / 4); i += kMidBlock) reinterpret_cast<float*>(s_tab.circ)[i] = csrc[i];
+        for (int i = lane; i < (int)(sizeof(s_tab.feat) / 4); i += kMidBlock) reinterpret_cast<float*>(s_tab.feat)[i] = fsrc[i];
         __syncthreads();
     }
     const LrmTolTables T{s_tab.circ, s_tab.feat};
     const uint32_t* seg_a = queue_a + (size_t)blockIdx.x * seg_cap;
     uint32_t* seg_b = queue_b + (size_t)blockIdx.x * seg_cap;
     uint32_t cnt = 0;
-    for (uint32_t k0 = 0; k0 < total; k0 += kFixBlock) { // whole wave iterates together (ballot below)
+    for (uint32_t k0 = 0; k0 < total; k0 += kMidBlock) { // whole wave iterates together (ballot below)
         const uint32_t k = k0 + lane;
         uint32_t doubt = 0;
         size_t i = 0;
@@ -776,8 +781,8 @@ hipError_t lrm_launch_dist_tolgrid(int op, const float* x, const float* y, const
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 #if !LRM_TOLGRID_MERGED
-    if (op == 2) hipLaunchKernelGGL(tol_mid_kernel<2>, dim3((unsigned)waves), dim3(kFixBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue_a, counts_a, queue_b, counts_b, seg_cap);
-    else hipLaunchKernelGGL(tol_mid_kernel<1>, dim3((unsigned)waves), dim3(kFixBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue_a, counts_a, queue_b, counts_b, seg_cap);
+    if (op == 2) hipLaunchKernelGGL(tol_mid_kernel<2>, dim3((unsigned)waves), dim3(kMidBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue_a, counts_a, queue_b, counts_b, seg_cap);
+    else hipLaunchKernelGGL(tol_mid_kernel<1>, dim3((unsigned)waves), dim3(kMidBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue_a, counts_a, queue_b, counts_b, seg_cap);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
 #endif

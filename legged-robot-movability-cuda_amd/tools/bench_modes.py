@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--reps", type=int, default=300)
     ap.add_argument("--modes", default="tol,fast,strict")
+    ap.add_argument("--cloud", default="cube", choices=["cube", "grid"],
+                    help="cube: config 2 (uniform in the leg's bounding cube); grid: the reference's planar bench grid (y = 0), random samples of it")
     args = ap.parse_args()
     import torch
     import lrm_amd
@@ -26,6 +28,10 @@ def main():
     for s in range(0, n, 2_000_000):
         e = min(n, s + 2_000_000)
         host[:, s:e] = (rng.random((e - s, 3), dtype=np.float32) * (hi - lo) + lo).T
+    if args.cloud == "grid":  # bench.cpp:109-120: x in [-100, 601], y = 0, z in [-100, 51]
+        host[0] = rng.uniform(-100, 601, n).astype(np.float32)
+        host[1] = 0
+        host[2] = rng.uniform(-100, 51, n).astype(np.float32)
     cloud = torch.from_numpy(host).cuda()
     x, y, z = cloud[0], cloud[1], cloud[2]
     leg = lrm_amd.get_M2_leg(0.0)
