@@ -16,8 +16,8 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--reps", type=int, default=300)
     ap.add_argument("--modes", default="tol,fast,strict")
-    ap.add_argument("--cloud", default="cube", choices=["cube", "grid"],
-                    help="cube: config 2 (uniform in the leg's bounding cube); grid: the reference's planar bench grid (y = 0), random samples of it")
+    ap.add_argument("--cloud", default="cube", choices=["cube", "grid", "reachable", "far"],
+                    help="cube: config 2 (uniform in the leg's bounding cube); grid: the reference's planar bench grid (y = 0), random samples of it; reachable / far: only reachable points (resampled from the cube) / only points beyond the workspace: the two ends of the lane divergence")
     args = ap.parse_args()
     import torch
     import lrm_amd
@@ -32,7 +32,22 @@ def main():
         host[0] = rng.uniform(-100, 601, n).astype(np.float32)
         host[1] = 0
         host[2] = rng.uniform(-100, 51, n).astype(np.float32)
+    if args.cloud == "far":
+        host[0] += 900.0
     cloud = torch.from_numpy(host).cuda()
+    if args.cloud == "reachable":  # keep the reachable points of a few cubes until n are collected
+        lrm_amd.set_mode(lrm_amd.MODE_FAST)
+        parts, have, seed = [], 0, 1
+        while have < n:
+            g = torch.Generator(device="cuda")
+            g.manual_seed(seed)
+            seed += 1
+            c = torch.rand((3, n), device="cuda", generator=g) * torch.tensor(hi - lo, device="cuda").view(3, 1) + torch.tensor(lo, device="cuda").view(3, 1)
+            m = lrm_amd.device.reach(c[0].contiguous(), c[1].contiguous(), c[2].contiguous(), lrm_amd.get_M2_leg(0.0))
+            keep = c[:, m.bool()]
+            parts.append(keep)
+            have += keep.shape[1]
+        cloud = torch.cat(parts, dim=1)[:, :n].contiguous()
     x, y, z = cloud[0], cloud[1], cloud[2]
     leg = lrm_amd.get_M2_leg(0.0)
     mask = torch.empty(n, dtype=torch.uint8, device="cuda")
