@@ -267,3 +267,33 @@ def test_tol_large_cloud_stays_in_its_fast_regime(lrm, torch_cuda):
     assert float(torch.nan_to_num(err, nan=0.0).max()) <= TOL
     print(f"5e7 points: tolerance mode {ms_tol:.3f} ms, bit-exact mode {ms_fast:.3f} ms")
     assert ms_tol < 0.85 * ms_fast  # 0.64 measured at cold clocks, 0.53 at steady clocks; 1.15 with the overflow
+
+
+def test_tol_non_finite_and_degenerate_points_take_the_bit_exact_path(lrm, torch_cuda):
+    """nan / inf / huge coordinates, the body origin, points exactly on the coxa axis, signed zeros and subnormals,
+    scattered through an ordinary cloud: the tolerance kernel must flag them (its bands are nan / inf, or the point is
+    inside the near-axis guard) and the fix-up must leave exactly what the bit-exact mode gives, nan patterns included."""
+    torch = torch_cuda
+    pts = random_cloud(20_000, seed=99)
+    special = np.array([[np.nan, 0, 0], [0, np.nan, 5], [1, 2, np.nan], [np.inf, 1, 2], [-np.inf, 0, 0], [0, np.inf, 0], [3, 4, -np.inf],
+                        [1e30, 1e30, -1e30], [3e38, 0, 0], [0, 0, 0], [-0.0, -0.0, -0.0], [1e-42, -1e-42, 1e-45],
+                        [181.0, 0.0, 0.0], [181.0, 0.0, 50.0], [181.0, 0.0, -300.0], [181.0, 1e-30, 10.0]], np.float32)
+    where = np.arange(len(special)) * 997 + 13
+    pts[where] = special
+    x, y, z = soa(torch, pts)
+    for leg in (lrm.get_M2_leg(0.0), lrm.get_moonbot_leg(0.0)):
+        lrm.set_mode(lrm.MODE_FAST)
+        m1, d1 = lrm.device.reach_dist(x, y, z, leg, None)
+        lrm.set_mode(lrm.MODE_TOL)
+        m2, d2 = lrm.device.reach_dist(x, y, z, leg, None)
+        torch.cuda.synchronize()
+        m1, d1, m2, d2 = m1.cpu().numpy(), d1.cpu().numpy().T, m2.cpu().numpy(), d2.cpu().numpy().T
+        assert np.array_equal(m1, m2)
+        finite_in = np.isfinite(special).all(axis=1) & (np.abs(special).max(axis=1) < 1e6)
+        # non-finite or huge input: the same bit patterns as the bit-exact mode, nan for nan
+        assert bits_equal(d1[where][~finite_in], d2[where][~finite_in]).all(), (d1[where], d2[where])
+        # everything else (the coxa axis of the moonbot leg is x = 181, y = 0; the M2 leg's axis is pitched): bit-identical or in tolerance
+        e = field_error(pts[where][finite_in], d2[where][finite_in], d1[where][finite_in], leg)
+        assert (bits_equal(d1[where][finite_in], d2[where][finite_in]).all(axis=1) | (e["metric"] <= TOL)).all()
+        e = field_error(np.delete(pts, where, 0), np.delete(d2, where, 0), np.delete(d1, where, 0), leg)
+        assert e["metric"].max() <= TOL
