@@ -428,6 +428,9 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     const uint32_t* __restrict__ counts, uint32_t nseg, uint32_t seg_cap, size_t main_stride) {
     __shared__ FixLds s_tab;
     __shared__ uint32_t s_pre[kSegPerWave + 1], s_cnt[kSegPerWave];
+    constexpr uint32_t kQueueAhead = 16;
+    static_assert(kSegPerWave * kQueueAhead <= kFixBlock, "one slot per thread");
+    __shared__ uint32_t s_q[kSegPerWave][kQueueAhead];
     const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kFixLegArg);
     const uint32_t seg0 = blockIdx.x * kSegPerWave;
     const int lane = threadIdx.x;
@@ -444,6 +447,12 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
         for (int i = lane; i < (int)(sizeof(s_tab.corners) / 16); i += kFixBlock) reinterpret_cast<uint4*>(s_tab.corners)[i] = csrc[i];
     }
     if (lane < kSegPerWave) s_cnt[lane] = (seg0 + lane < nseg) ? counts[seg0 + lane] : 0u;
+    // the first kQueueAhead slots of every segment (usually all that is queued: 2-3 points per segment) come along with the
+    // counts instead of one round trip later; slots beyond a segment's count hold stale indices that are never used
+    if (lane < kSegPerWave * kQueueAhead) {
+        const uint32_t sj = (uint32_t)lane / kQueueAhead, so = (uint32_t)lane % kQueueAhead;
+        s_q[sj][so] = (seg0 + sj < nseg && so < seg_cap) ? queue[(size_t)(seg0 + sj) * seg_cap + so] : 0u;
+    }
     __syncthreads();
     LRM_TRACE_FIX(1);
     if (lane == 0) {
@@ -497,7 +506,8 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
         int j = 0;
 #pragma unroll
         for (int t = 1; t < kSegPerWave; t++) j += (s_pre[t] <= k) ? 1 : 0; // segments with nothing queued share a prefix
-        redo((size_t)queue[(size_t)(seg0 + j) * seg_cap + (k - s_pre[j])]);
+        const uint32_t off = k - s_pre[j];
+        redo((size_t)(off < kQueueAhead ? s_q[j][off] : queue[(size_t)(seg0 + j) * seg_cap + off]));
 #if defined(LRM_FIX_TRACE)
         if (lane == 0 && pass < 4 && blockIdx.x < 4096) g_fix_trace[blockIdx.x * 8 + 3 + pass] = wall_clock64();
         pass++;
