@@ -105,14 +105,17 @@ def cpu_baseline(sample_points, leg):
     single = n1 / (time.perf_counter() - t0)
     cores = min(os.cpu_count() or 1, 16)
     parts = [pts[i[0]:i[-1] + 1] for i in np.array_split(np.arange(n), cores)]
+    dts = []
     with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL during the C loops
-        t0 = time.perf_counter()
-        list(ex.map(both, parts))
-        dt = time.perf_counter() - t0
+        for _ in range(3):                 # three passes over the sample (~10 CPU-seconds), median
+            t0 = time.perf_counter()
+            list(ex.map(both, parts))
+            dts.append(time.perf_counter() - t0)
+    dt = float(np.median(dts))
     out = {"value": n / dt, "unit": "leg-target evaluations/s (reach+dist)", "cores": cores, "kind": "port",
            "impl": "liblrm.so lrm_reach_cpu + lrm_dist_cpu (the apply_reach_cpu / apply_dist_cpu drop-ins; bit-identical "
                    "to the reference's host path; NOT the RBDL baseline, which is rbdl_equivalent below)",
-           "sample": f"first {n} points of the same cloud, reach loop + distance loop, {cores} threads (static split); "
+           "sample": f"first {n} points of the same cloud, reach loop + distance loop, {cores} threads (static split), median of 3 passes; "
                      f"single thread on {n1} points: {single:.3e}/s",
            "single_thread_value": single}
     # apply_RBDL's work (rbdl_benchmark.cpp:18-111), 3 repeats as setting_bench.h:7, on <= 1e5 points
