@@ -63,7 +63,8 @@ __device__ __forceinline__ bool in_box(LrmVec3 v, float hx, float hy, float hz) 
 // that leg reaches (`spheres`, from LrmCompiledLeg::pair_center / pair_r2 turned into this frame: the nearest boundary
 // point lies in the closure of the reachable set, so |distance vector| >= distance to the sphere).  With `near` such legs,
 // reach_count <= near and cross_count <= near: when near < LegNumberForStab and near <= LegCount - LegNumberForStab the
-// item contributes `reach = parent_valid`, no edge -- without evaluating anything.  Deep in the tree (small boxes, four
+// item contributes `reach = parent_valid`, no edge -- without evaluating anything; and inside an item that is evaluated, the
+// legs beyond their own sphere are skipped (they neither reach nor cross).  Deep in the tree (small boxes, four
 // legs mounted 45 degrees apart) that is most of the footholds inside the elongated parent box.
 template <bool kFast>
 __device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 vect, float h2, float hd, const LrmCompiledLeg* __restrict__ legs,
@@ -71,10 +72,13 @@ __device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 v
     uint32_t mine = 0;
     for (int a = 0; a < ch.n_angles; a++) {
         int near = 0;
+        uint32_t near_bits = 0;
         for (int l = 0; l < leg_count; l++) {
             const float4 sp = spheres[a * leg_count + l];
             const float ex = vect.x - sp.x, ey = vect.y - sp.y, ez = vect.z - sp.z, rr = sp.w + hd;
-            near += (ex * ex + ey * ey + ez * ez < rr * rr) ? 1 : 0;
+            const bool in = ex * ex + ey * ey + ez * ez < rr * rr;
+            near += in ? 1 : 0;
+            near_bits |= in ? (1u << l) : 0u;
         }
         if (near < legs_for_stab && near <= leg_count - legs_for_stab) {
             mine |= ch.parent_valid ? 3u : 0u;
@@ -82,6 +86,7 @@ __device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 v
         }
         int reach_count = 0, cross_count = 0;
         for (int l = 0; l < leg_count; l++) {
+            if (!((near_bits >> l) & 1u)) continue; // beyond this leg's sphere: it neither reaches nor crosses (same argument)
             const LrmCompiledLeg& L = legs[a * leg_count + l];
             LrmVec3 v = vect;
             bool sub;
