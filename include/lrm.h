@@ -51,7 +51,8 @@ extern "C" {
  *                  boundary feature as the reference's: |d - d_ref| <= 1e-5 max(|d_ref|, (|p| + body) / 8) per point
  *                  (about 10 ulp of the coordinates at most; tests/tolcheck.py).  Points with any decision inside its
  *                  error band are re-evaluated by the LRM_MODE_FAST code in a second small launch and are
- *                  bit-identical.  Applies to the distance / fused entry points; reach-only and pair kernels
+ *                  bit-identical.  Applies to the distance / fused entry points, host buffers (lrm_dist, lrm_reach_dist: the
+ *                  apply_kernel boundary) and device buffers alike; reach-only and pair kernels
  *                  run as in LRM_MODE_FAST.  Legs outside the mode's eligibility use LRM_MODE_FAST. */
 #define LRM_MODE_TOL 2
 

@@ -161,6 +161,23 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
     return LRM_OK;
 }
 
+// distance / fused launch on the float3 arrays of the apply_kernel boundary in the current mode
+int launch_dist_aos_mode(int op, const float* xyz, size_t n, const LrmLegDimensions& leg, const float* quat, const LrmCompiledLeg& L,
+                         uint8_t* mask, float* dxyz, void* stream) {
+    if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xc0000000ull) {
+        const LrmTolLeg& TL = tol_entry(leg, quat, L).tl;
+        if (TL.tol_ok) {
+            uint32_t* w = nullptr;
+            const int rc = tol_workspace(lrm_tol_queue_words(n), stream, &w);
+            if (rc != LRM_OK) return rc;
+            HIP_TRY(lrm_launch_dist_tol_aos(op, xyz, n, L, TL, mask, dxyz, w, (hipStream_t)stream), "tolerance-mode launch");
+            return LRM_OK;
+        }
+    }
+    HIP_TRY(lrm_launch_dist_aos(op, xyz, n, L, mask, dxyz, g_mode != LRM_MODE_STRICT, (hipStream_t)stream), "Kernel launch");
+    return LRM_OK;
+}
+
 // RAII device buffer for the host-buffer entry points
 struct DevBuf {
     void* p = nullptr;
@@ -203,8 +220,11 @@ int host_apply(int op, const float* xyz, size_t n, const LrmLegDimensions* leg, 
     HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
     if (n) {
         if (op == 0) HIP_TRY(lrm_launch_reach_aos(d_in.as<float>(), n, L, d_mask.as<uint8_t>(), g_mode != LRM_MODE_STRICT, nullptr), "Kernel launch");
-        else HIP_TRY(lrm_launch_dist_aos(op, d_in.as<float>(), n, L, want_mask ? d_mask.as<uint8_t>() : nullptr,
-                                         d_out.as<float>(), g_mode != LRM_MODE_STRICT, nullptr), "Kernel launch");
+        else {
+            const int rc = launch_dist_aos_mode(op, d_in.as<float>(), n, *leg, quat_or_default(quat), L, want_mask ? d_mask.as<uint8_t>() : nullptr,
+                                                d_out.as<float>(), nullptr);
+            if (rc != LRM_OK) return rc;
+        }
     }
     HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
     HIP_TRY(hipEventSynchronize(ev.b), "Kernel launch");
@@ -478,8 +498,7 @@ int lrm_dist_aos_dev(const float* xyz, size_t n, const LrmLegDimensions* leg, co
     if (n == 0) return LRM_OK;
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    HIP_TRY(lrm_launch_dist_aos(1, xyz, n, L, valid, dxyz, g_mode != LRM_MODE_STRICT, (hipStream_t)stream), "dist launch");
-    return LRM_OK;
+    return launch_dist_aos_mode(1, xyz, n, *leg, quat_or_default(quat), L, valid, dxyz, stream);
 }
 
 // ---- body x target aggregation ---------------------------------------------------------

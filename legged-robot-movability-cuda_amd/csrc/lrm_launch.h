@@ -14,6 +14,8 @@ hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const flo
 // `st`.  workspace: lrm_tol_queue_words(n) uint32 of device memory owned by the caller for the duration of both
 // launches (contents are rewritten by every call; no initialisation needed).
 size_t lrm_tol_queue_words(size_t n);
+hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, uint8_t* mask,
+                                   float* dxyz, uint32_t* workspace, hipStream_t st);
 hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz,
                                uint32_t* workspace, hipStream_t st);

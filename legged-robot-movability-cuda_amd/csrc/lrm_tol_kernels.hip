@@ -203,7 +203,8 @@ __global__ __launch_bounds__(kBlock, 7) void dist_tol_kernel(
 // worth per 256 points instead of all four waves), and take (du, dz, valid, doubt) back.  Everything else, and every
 // global access, stays with the owning lane: coalesced as before.  Two barriers per iteration.
 // ------------------------------------------------------------------------------------------------------------
-template <int kOp>
+// kAoS: x is the float3 array of the apply_kernel boundary (y, z unused), dx the float3 output (dy, dz unused)
+template <int kOp, bool kAoS = false>
 __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x;
         const size_t rb0 = (size_t)blockIdx.x * kBlock;
         const uint32_t to = lrm_opaque(threadIdx.x * 4u);
-        if (i0 < n) p_next = LrmVec3{lrm_at(x + rb0, to), lrm_at(y + rb0, to), lrm_at(z + rb0, to)};
+        if (i0 < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb0, 3u * to), lrm_at(x + 3 * rb0, 3u * to + 4u), lrm_at(x + 3 * rb0, 3u * to + 8u)}
+                                  : LrmVec3{lrm_at(x + rb0, to), lrm_at(y + rb0, to), lrm_at(z + rb0, to)};
     }
 #endif
     {
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         LrmVec3 p = p_next;
 #else
         LrmVec3 p{0.f, 0.f, 0.f};
-        if (live) p = LrmVec3{lrm_at(x + rbase, toff), lrm_at(y + rbase, toff), lrm_at(z + rbase, toff)};
+        if (live) p = kAoS ? LrmVec3{lrm_at(x + 3 * rbase, 3u * toff), lrm_at(x + 3 * rbase, 3u * toff + 4u), lrm_at(x + 3 * rbase, 3u * toff + 8u)}
+                           : LrmVec3{lrm_at(x + rbase, toff), lrm_at(y + rbase, toff), lrm_at(z + rbase, toff)};
 #endif
         // ---- A: first candidate ----
         const LrmTolPoint S = lrm_tol_prologue(L, p);
@@ -280,7 +283,8 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
             const uint32_t i_next = i + stride;
             const size_t rb_next = rbase + stride;
             p_next = LrmVec3{0.f, 0.f, 0.f};
-            if (i_next < n) p_next = LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
+            if (i_next < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
+                                          : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
         }
 #endif
 #if defined(LRM_TOL_EXP_NOB)
@@ -316,9 +320,15 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         const bool m = lrm_tol_finish(L, S, A, need, B, p, doubt) && live;
         doubt = live ? (doubt & 0xffffu) : 0u;
         if (live) {
-            lrm_at(dx + rbase, toff) = p.x;
-            lrm_at(dy + rbase, toff) = p.y;
-            lrm_at(dz + rbase, toff) = p.z;
+            if (kAoS) {
+                lrm_at(dx + 3 * rbase, 3u * toff) = p.x;
+                lrm_at(dx + 3 * rbase, 3u * toff + 4u) = p.y;
+                lrm_at(dx + 3 * rbase, 3u * toff + 8u) = p.z;
+            } else {
+                lrm_at(dx + rbase, toff) = p.x;
+                lrm_at(dy + rbase, toff) = p.y;
+                lrm_at(dz + rbase, toff) = p.z;
+            }
             if (mask) lrm_at(mask + rbase, tid_o) = m;
         }
         if (bits && i < (uint32_t)((n + 63) & ~(size_t)63)) { // wave-uniform
@@ -420,7 +430,7 @@ struct FixLds {
 
 // One wave: the segments [blockIdx.x * kSegPerWave, +kSegPerWave) of a dist_tol_kernel launch of `nseg` workgroups
 // with grid stride `main_stride` points.
-template <int kOp>
+template <int kOp, bool kAoS = false>
 __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
@@ -472,12 +482,18 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     constexpr int kPerPass = kFixBlock / 2; // points per pass of the wave
     const int slot = lane >> 1, cand = lane & 1;
     auto redo = [&](size_t i) { // both lanes of the pair come here with the same i
-        LrmVec3 p{x[i], y[i], z[i]};
+        LrmVec3 p = kAoS ? LrmVec3{x[3 * i], x[3 * i + 1], x[3 * i + 2]} : LrmVec3{x[i], y[i], z[i]};
         const bool m = lrm_redo_pair<kOp>(L, T, p, cand);
         if (cand == 0) {
-            dx[i] = p.x;
-            dy[i] = p.y;
-            dz[i] = p.z;
+            if (kAoS) {
+                dx[3 * i] = p.x;
+                dx[3 * i + 1] = p.y;
+                dx[3 * i + 2] = p.z;
+            } else {
+                dx[i] = p.x;
+                dy[i] = p.y;
+                dz[i] = p.z;
+            }
             if (mask) mask[i] = m;
             if (bits) patch_bit(bits, i, m);
         }
@@ -486,6 +502,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     constexpr int kPerPass = kFixBlock;
     const int slot = lane;
     auto redo = [&](size_t i) {
+        static_assert(!kAoS, "the one-lane-per-point fix-up is SoA only");
         LrmVec3 p{x[i], y[i], z[i]};
         bool m = false;
         if (kOp == 2) lrm_reach_dist_global_filtered(L, T, p, m);
@@ -736,6 +753,28 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
     if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
     else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
     return hipGetLastError();
+}
+
+// The same two launches on the float3 arrays of the apply_kernel boundary (cross_compiled.cu:33-79): no bit words.
+hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, uint8_t* mask,
+                                   float* dxyz, uint32_t* workspace /* lrm_tol_queue_words(n) uint32 */, hipStream_t st) {
+#if LRM_TOL_STAGED && LRM_TOL_FIX_PAIR
+    const size_t blocks = tol_main_blocks(n);
+    uint32_t* counts = workspace;
+    uint32_t* queue = workspace + blocks;
+    if (op == 2) hipLaunchKernelGGL((dist_tol_staged_kernel<2, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts);
+    else hipLaunchKernelGGL((dist_tol_staged_kernel<1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
+    const size_t stride = blocks * kBlock;
+    if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    return hipGetLastError();
+#else
+    (void)op; (void)xyz; (void)n; (void)L; (void)TL; (void)mask; (void)dxyz; (void)workspace; (void)st;
+    return hipErrorNotSupported;
+#endif
 }
 
 // ---- plane-table variant ------------------------------------------------------------------------------------

@@ -229,4 +229,4 @@ def test_tolerance_kernels_keep_their_register_budget(lrm):
         assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, name
         assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, name
         assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 8, name
-    assert seen == 2  # kOp 1 and 2
+    assert seen == 4  # kOp 1 and 2, SoA and float3 layout

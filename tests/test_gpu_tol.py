@@ -297,3 +297,15 @@ def test_tol_non_finite_and_degenerate_points_take_the_bit_exact_path(lrm, torch
         assert (bits_equal(d1[where][finite_in], d2[where][finite_in]).all(axis=1) | (e["metric"] <= TOL)).all()
         e = field_error(np.delete(pts, where, 0), np.delete(d2, where, 0), np.delete(d1, where, 0), leg)
         assert e["metric"].max() <= TOL
+
+
+@pytest.mark.parametrize("name", golden_cases("cube") + golden_cases("grid"))
+def test_tol_host_buffer_api_of_the_apply_kernel_boundary(lrm, name):
+    """lrm_dist / lrm_reach_dist on host float3 arrays (the apply_kernel drop-ins) in the tolerance mode: the same two
+    kernels instantiated for the float3 layout."""
+    c = load_case(name)
+    d, v, ms = lrm.apply_dist(c["points"], c["leg"], c["quat"])
+    m2, d2, ms2 = lrm.apply_reach_dist(c["points"], c["leg"], c["quat"])
+    assert ms > 0 and ms2 > 0
+    check_outputs(c["points"], v, v, d, None, c["valid"], c["valid"], c["dist"], c["leg"])
+    check_outputs(c["points"], m2, None, d2, None, c["mask"], c["valid"], c["dist"], c["leg"])
