@@ -309,3 +309,15 @@ def test_tol_host_buffer_api_of_the_apply_kernel_boundary(lrm, name):
     assert ms > 0 and ms2 > 0
     check_outputs(c["points"], v, v, d, None, c["valid"], c["valid"], c["dist"], c["leg"])
     check_outputs(c["points"], m2, None, d2, None, c["mask"], c["valid"], c["dist"], c["leg"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 257, 4099])
+def test_tol_host_buffer_api_ragged_sizes(lrm, oracle, n):
+    pts = random_cloud(n, seed=n + 5)
+    leg = lrm.get_moonbot_leg(1.1)
+    q = (0.97, 0.1, -0.2, 0.05)
+    want_d, want_v = oracle.dist(pts, leg, q)
+    d, v, _ = lrm.apply_dist(pts, leg, q)
+    m2, d2, _ = lrm.apply_reach_dist(pts, leg, q)
+    check_outputs(pts, v, v, d, None, want_v, want_v, want_d, leg)
+    check_outputs(pts, m2, None, d2, None, oracle.reach(pts, leg, q), want_v, want_d, leg)
