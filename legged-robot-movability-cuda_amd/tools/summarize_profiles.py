@@ -18,7 +18,8 @@ import re
 import sys
 
 STEP_KERNELS = {
-    "tol": ["dist_tol_staged_kernel<2>", "dist_tol_kernel<2>", "tol_fixup_kernel<2>"],  # whichever main kernel the build launches
+    # whichever main kernel the build launches (the second template argument is the layout: false = one array per component)
+    "tol": ["dist_tol_staged_kernel<2, false>", "dist_tol_staged_kernel<2>", "dist_tol_kernel<2>", "tol_fixup_kernel<2, false>", "tol_fixup_kernel<2>"],
     "fast": ["dist_soa_kernel<2, true>"],
     "strict": ["dist_soa_kernel<2, false>"],
 }
