@@ -144,6 +144,12 @@ def _oct_worker(rank, world, port, ret):
         dim = lrm_amd.get_M2_leg(0.0)
         st = settings(lrm_amd, 800.0, 5, stab=3)
         got, _ = lrm_amd.shard.apply_oct_sharded(f, dim, st)
+        # the same with the footholds already on the device (lrm_apply_oct_dev through the exchange callback)
+        import numpy as np
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(f.T)).cuda()
+        dev, _ = lrm_amd.shard.apply_oct_sharded((t[0], t[1], t[2]), dim, st)
+        assert got.tobytes() == dev.tobytes()
         ret[rank] = got.tobytes()
     finally:
         dist.destroy_process_group()
