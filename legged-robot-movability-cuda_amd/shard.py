@@ -77,9 +77,10 @@ def reach_bits_sharded(compute_local_bits, n, group=None):
 # kernel of step k + 1.  The local computation is injected, so the control flow runs under gloo on the CPU.
 # ---------------------------------------------------------------------------------------------------
 class BitsGatherLoop:
-    def __init__(self, n, device="cuda", group=None, host_staging=False):
+    def __init__(self, n, device="cuda", group=None, host_staging=False, time_gather=False):
         """n: points of the whole cloud.  device: where the word buffers live ("cuda" for RCCL, "cpu" for gloo).
-        host_staging: compute on `device` but gather through host memory (gloo rehearsals of a GPU run)."""
+        host_staging: compute on `device` but gather through host memory (gloo rehearsals of a GPU run).
+        time_gather: keep the duration of every gather (events on the side stream / host clock): gather_ms()."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -98,6 +99,8 @@ class BitsGatherLoop:
         self.gathered = [torch.zeros(max(self.per_words, 1) * self.world, dtype=torch.int64, device=gdev) for _ in range(2)]
         self.comm_stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
         self.free = [None, None]  # event after which words[b] may be rewritten
+        self.time_gather = time_gather and self.world > 1
+        self._gather_events, self._gather_host_ms = [], []
 
     def step(self, k, compute):
         """compute(words_view, lo, hi) launches the local evaluation of points [lo, hi) writing words_view
@@ -114,16 +117,39 @@ class BitsGatherLoop:
             ready.record()
             self.comm_stream.wait_event(ready)
             with torch.cuda.stream(self.comm_stream):
-                self._gather(b)
+                if self.time_gather and not self.host_staging:
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record()
+                    self._gather(b)
+                    t1.record()
+                    self._gather_events.append((t0, t1))
+                else:
+                    self._gather(b)
                 self.free[b] = torch.cuda.Event()
                 self.free[b].record()
         else:
             self._gather(b)
         return b
 
+    def reset_gather_timing(self):
+        self._gather_events, self._gather_host_ms = [], []
+
+    def gather_ms(self):
+        """mean duration of the gathers since the last reset (None without time_gather or with one rank); call after a
+        device synchronisation"""
+        if not self.time_gather:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self._gather_events] + self._gather_host_ms
+        return float(sum(ms) / len(ms)) if ms else None
+
     def _gather(self, b):
+        import time
+        host_timed = self.time_gather and (self.host_staging or not self.cuda)
+        t0 = time.perf_counter() if host_timed else 0.0
         src = self.words[b].cpu() if self.host_staging else self.words[b]
         self.dist.all_gather_into_tensor(self.gathered[b], src, group=self.group)
+        if host_timed:
+            self._gather_host_ms.append((time.perf_counter() - t0) * 1e3)
 
     def result(self, b):
         """The ceil(n / 64) words of the whole cloud from buffer b (synchronises the side stream)."""

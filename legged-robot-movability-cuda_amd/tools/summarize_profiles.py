@@ -14,8 +14,12 @@ tolerance kernel + its fix-up)."""
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from srchash import kernel_src_sha  # noqa: E402  (the tree the passes were collected from: run this on the same snapshot)
 
 STEP_KERNELS = {
     # whichever main kernel the build launches (the second template argument is the layout: false = one array per component)
@@ -50,7 +54,7 @@ def main():
                          "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
     step = [k for k in STEP_KERNELS[mode] if k in kernels]
     traffic = {
-        "points_per_launch": points, "mode": mode, "step_kernels": step,
+        "points_per_launch": points, "mode": mode, "step_kernels": step, "kernel_src_sha": kernel_src_sha(),
         "step_hbm_bytes": sum(kernels[k]["hbm_bytes_per_launch"] for k in step),
         "algorithmic_bytes": 25 * points + points // 8,
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
@@ -68,7 +72,7 @@ def main():
                      "SQ_INSTS_SALU_mean": sum(salu.get(name, [0])) / max(len(salu.get(name, [0])), 1),
                      "SQ_WAVES_mean": sum(waves.get(name, [0])) / max(len(waves.get(name, [0])), 1)}
     step_valu = sum(per[k]["SQ_INSTS_VALU_mean"] for k in step if k in per)
-    out = {"mode": mode, "points_per_launch": points, "step_kernels": step,
+    out = {"mode": mode, "points_per_launch": points, "step_kernels": step, "kernel_src_sha": kernel_src_sha(),
            "valu_insts_per_eval": step_valu * 64.0 / points,  # SQ_INSTS_VALU counts wave instructions: 64 lanes each
            "salu_insts_per_eval": sum(per[k]["SQ_INSTS_SALU_mean"] for k in step if k in per) * 64.0 / points,
            "note": "wave-level VALU instructions issued per evaluated point (all launches of one step); the kernel's own issue "

@@ -1,5 +1,11 @@
 """The acceptance metric of LRM_MODE_TOL (include/lrm.h), shared by the CPU and GPU tests.
 
+FROZEN (round 3): the metric below is part of the mode's contract in include/lrm.h and does not move when a test
+fails -- a failing point is a bug in the kernel (or goes to the bit-exact fix-up), not a reason to widen the floor.
+It is a FLOORED reading of BASELINE.json's "1e-5 relative", i.e. a deviation from the literal text for short vectors;
+the literal relative error is asserted where float32 can deliver it (|d_ref| >= 16 mm: tests/test_gpu_tol.py) and
+reported everywhere else (bench.py "tolerance_check").  LRM_MODE_FAST meets the literal text (tolerance 0).
+
 BASELINE.json asks for the distance field "within 1e-5 relative".  The field is a difference of positions:
 d = p - (nearest boundary point), and the reference computes it in the coxa frame: its first operation on the point is
 `x -= body` (place_over_coxa, one_leg.cu:13), so the coordinates it works with have magnitude up to |p| + body in
