@@ -259,6 +259,23 @@ int lrm_apply_oct_dev(const float* fx, const float* fy, const float* fz, size_t 
                       int rank, int world, LrmOctExchange exchange, void* user);
 const char* lrm_octree_last_error(void);
 
+/* ---- several GPUs behind the apply_kernel boundary (one process, one host thread) ------------------------------
+ * New capability: the reference runs on device 0 only (several_leg.cu:800; apply_kernel cross_compiled.cu:33-79).
+ * lrm_shard_bounds: owner `rank` of `world` gets items [lo, hi) of n, boundaries multiples of `align` (64 for point
+ *   clouds: no 64-point ballot word straddles two owners); ceil(n / world) rounded up to `align` per owner, the last
+ *   owners may be short or empty.  The Python side (lrm_amd.shard.shard_bounds) uses the same arithmetic.
+ * lrm_reach_dist_multi: lrm_reach_dist with the cloud cut into those shards over `ndev` devices (`devices`: their
+ *   ordinals, NULL = 0 .. ndev-1): per device one stream, its slice of the input, the fused kernels of the current
+ *   mode, the reach bytes packed into ballot words; the words are all-gathered with RCCL (ncclCommInitAll once per
+ *   device set + one grouped ncclAllGather per call; librccl.so is opened on first use with ndev > 1), so that every
+ *   device holds the bit-packed mask of the whole cloud (BASELINE config 4's exchange step).  mask_out[n] /
+ *   dxyz_out[3 n] as lrm_reach_dist; bits_out: NULL or ceil(n / 64) words, the gathered mask as devices[0] holds it;
+ *   ms_per_dev: NULL or [ndev] kernel milliseconds per device.  lrm_multi_release frees the cached communicators. */
+int lrm_shard_bounds(size_t n, int world, int rank, size_t align, size_t* lo_out, size_t* hi_out);
+int lrm_reach_dist_multi(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat, int ndev,
+                         const int* devices, uint8_t* mask_out, float* dxyz_out, uint64_t* bits_out, float* ms_per_dev);
+void lrm_multi_release(void);
+
 /* ---- diagnostics -------------------------------------------------------------------------
  * The glibc-exact atan2f / sincosf of the strict kernels (csrc/lrm_exact_math.h) applied to
  * arrays: at2[i] = atan2f(a[i], b[i]); (sn[i], cs[i]) = sincosf(a[i]).  Host build and device
@@ -287,6 +304,10 @@ int lrm_dbg_tol_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg
  * point in full); *n_fine_out (may be NULL) = refined cells of the table. */
 int lrm_dbg_tolgrid_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                          uint8_t* mask_out, float* dxyz_aos_out, uint32_t* doubt_out, uint32_t* n_fine_out);
+/* As lrm_dbg_tol_host with the plane table with deferred decisions (csrc/lrm_toltab.cpp) in place of the full plane
+ * evaluation; doubt bit 0x100 = a cell without an answer.  stats_out[4] (or NULL): rows, validity rows, refined cells, bytes. */
+int lrm_dbg_toltab_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+                        uint8_t* mask_out, float* dxyz_out, uint32_t* doubt_out, uint32_t* stats_out);
 /* After a device call that took the plane-table path of LRM_MODE_TOL (>= 5e5 points): points of that call, how
  * many of them needed the full evaluation, how many the bit-exact code.  Synchronises the device. */
 int lrm_dbg_tol_queue_counts(uint64_t* n_points, uint64_t* n_full, uint64_t* n_exact);

@@ -87,6 +87,25 @@ inline float apply_kernel(const Array<float3> input, const LegDimensions dim,
     return ms;
 }
 
+// apply_kernel_multi: NEW (the reference is single-device, several_leg.cu:800): the fused reach + distance of one cloud
+// over `ndev` GPUs of this process -- contiguous 64-point-aligned shards, one stream per device, RCCL all-gather of the
+// bit-packed reach mask (lrm_reach_dist_multi).  Same ownership rules as apply_kernel (cross_compiled.cu:33-79): the
+// caller owns all four arrays; gathered_bits (may be {0, nullptr}) receives ceil(n / 64) words.  Returns the largest
+// per-device kernel time in ms.
+inline float apply_kernel_multi(const Array<float3> input, const LegDimensions dim, int ndev, Array<bool> const reach_out,
+                                Array<float3> const dist_out, Array<unsigned long long> const gathered_bits = {0, nullptr}) {
+    static_assert(sizeof(bool) == 1 && sizeof(unsigned long long) == 8, "byte masks, 64-bit ballot words");
+    float ms[64] = {0.f};
+    if (ndev < 1 || ndev > 64) lrm_compat_detail::die("apply_kernel_multi");
+    lrm_compat_detail::check(lrm_reach_dist_multi(&input.elements->x, input.length, &dim, &quatTest.x, ndev, nullptr,
+                                                  reinterpret_cast<uint8_t*>(reach_out.elements), &dist_out.elements->x,
+                                                  reinterpret_cast<uint64_t*>(gathered_bits.elements), ms),
+                             "Kernel launch");
+    float worst = 0.f;
+    for (int d = 0; d < ndev; d++) worst = ms[d] > worst ? ms[d] : worst;
+    return worst;
+}
+
 // apply_reach_cpu / apply_dist_cpu, cross_compiled.cu:163-181 (return ms as double)
 inline double apply_reach_cpu(const Array<float3> input, const LegDimensions dim, Array<bool> const output) {
     double ms = 0;

@@ -83,6 +83,9 @@ def load():
         "lrm_dbg_tol_ok": [vp, vp],
         "lrm_dbg_tol_queue_counts": [vp, vp, vp],
         "lrm_dbg_tolgrid_host": [vp, sz, vp, vp, vp, vp, vp, vp],
+        "lrm_dbg_toltab_host": [vp, sz, vp, vp, vp, vp, vp, vp],
+        "lrm_shard_bounds": [sz, C.c_int, C.c_int, sz, vp, vp],
+        "lrm_reach_dist_multi": [vp, sz, vp, vp, C.c_int, vp, vp, vp, vp, vp],
         "lrm_dbg_pair_sphere": [vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
         "lrm_dbg_exact_math_dev": [vp, vp, sz, vp, vp, vp, vp],
@@ -110,6 +113,8 @@ def load():
     L.lrm_apply_oct_dev.restype = C.c_int
     L.lrm_rotate_leg_data.argtypes = [vp, vp, vp]
     L.lrm_rotate_leg_data.restype = None
+    L.lrm_multi_release.argtypes = []
+    L.lrm_multi_release.restype = None
     _lib = L
     return L
 
@@ -206,6 +211,29 @@ def apply_reach_dist(xyz, leg, quat=None):
     check(load().lrm_reach_dist(_ptr(xyz), len(xyz), _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(m), _ptr(d),
                                 C.addressof(ms)))
     return m, d, ms.value
+
+
+def shard_bounds(n, world, rank, align=64):
+    """lrm_shard_bounds: the C ABI's shard arithmetic (equal to lrm_amd.shard.shard_bounds)"""
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    check(load().lrm_shard_bounds(n, world, rank, align, C.addressof(lo), C.addressof(hi)))
+    return int(lo.value), int(hi.value)
+
+
+def apply_reach_dist_multi(xyz, leg, quat=None, ndev=1, devices=None, want_bits=True):
+    """lrm_reach_dist_multi: the fused kernels over ndev devices of this process + RCCL gather of the bit words
+    -> (mask, vectors, gathered words or None, kernel ms per device)"""
+    xyz = _f32(xyz, (-1, 3))
+    n = len(xyz)
+    d = np.zeros_like(xyz)
+    m = np.zeros(n, np.uint8)
+    bits = np.zeros((n + 63) // 64, np.uint64) if want_bits else None
+    ms = np.zeros(ndev, np.float32)
+    devs = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+    check(load().lrm_reach_dist_multi(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), ndev,
+                                      None if devs is None else _ptr(devs), _ptr(m), _ptr(d),
+                                      None if bits is None else _ptr(bits), _ptr(ms)))
+    return m, d, bits, ms
 
 
 # ---- CPU entry points (apply_reach_cpu / apply_dist_cpu, cross_compiled.cu:163-181) --------
@@ -358,6 +386,17 @@ def dbg_tol_host(xyz, leg, quat=None):
     check(load().lrm_dbg_tol_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d),
                                   _ptr(doubt)))
     return mask, d, doubt
+
+
+def dbg_toltab_host(xyz, leg, quat=None):
+    """LRM_MODE_TOL on the host with the plane table with deferred decisions -> (mask, vectors, doubt bits, table stats)"""
+    xyz = _f32(xyz, (-1, 3))
+    n = len(xyz)
+    mask, d, doubt = np.zeros(n, np.uint8), np.zeros_like(xyz), np.zeros(n, np.uint32)
+    stats = np.zeros(4, np.uint32)
+    check(load().lrm_dbg_toltab_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d),
+                                     _ptr(doubt), _ptr(stats)))
+    return mask, d, doubt, dict(rows=int(stats[0]), vrows=int(stats[1]), refined=int(stats[2]), bytes=int(stats[3]))
 
 
 def dbg_tolgrid_host(xyz, leg, quat=None):

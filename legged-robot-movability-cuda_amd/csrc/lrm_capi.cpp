@@ -50,8 +50,11 @@ struct TolKey {
 };
 struct TolEntry {
     LrmTolLeg tl;
-    std::vector<uint8_t> grid;     // the plane table (lrm_build_tol_grid), built on first use
+    std::vector<uint8_t> grid;     // the first-generation plane table (lrm_build_tol_grid), built on first use
     std::map<int, uint8_t*> dev;   // its device copies, by device ordinal
+    std::vector<uint8_t> tab;      // the plane table with deferred decisions (lrm_build_tol_tab), built on first use
+    int tab_state = 0;             // 0 not built yet, 1 built, -1 this leg has none (too many rows)
+    std::map<int, uint8_t*> tab_dev;
 };
 std::map<TolKey, TolEntry> g_tol_cache;
 TolEntry& tol_entry(const LrmLegDimensions& leg, const float* quat, const LrmCompiledLeg& L) {
@@ -62,7 +65,10 @@ TolEntry& tol_entry(const LrmLegDimensions& leg, const float* quat, const LrmCom
     if (it != g_tol_cache.end()) return it->second;
     if (g_tol_cache.size() >= 64) { // a sweep over many orientations: start over (device copies are released)
         for (auto& e : g_tol_cache)
+        {
             for (auto& d : e.second.dev) (void)hipFree(d.second);
+            for (auto& d : e.second.tab_dev) (void)hipFree(d.second);
+        }
         g_tol_cache.clear();
     }
     TolEntry& e = g_tol_cache[k];
@@ -113,6 +119,36 @@ bool tol_plane_table_enabled() {
     }();
     return on;
 }
+// The table kernel (dist_tab_kernel) is the default of LRM_MODE_TOL from LRM_TOLTAB_MIN_POINTS points on (building the
+// table costs a few milliseconds of host geometry per (leg, orientation)); LRM_TOL_TABLE=0 in the environment keeps
+// the staged kernel (A/B runs).
+#ifndef LRM_TOLTAB_MIN_POINTS
+#define LRM_TOLTAB_MIN_POINTS 200000
+#endif
+// LRM_TOL_TABLE: "0" never, "2" for every size (tests), anything else / unset: from LRM_TOLTAB_MIN_POINTS points on
+bool tol_tab_wanted(size_t n) {
+    const char* e = std::getenv("LRM_TOL_TABLE");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '2') return n > 0;
+    return n >= (size_t)LRM_TOLTAB_MIN_POINTS;
+}
+// device copy of the table of E on the current device, or null (no table for this leg); rc != LRM_OK on a HIP error
+int tol_tab_device(TolEntry& E, const uint8_t** out) {
+    *out = nullptr;
+    if (E.tab_state == 0) E.tab_state = lrm_build_tol_tab(E.tl, &E.tab) ? 1 : -1;
+    if (E.tab_state < 0) return LRM_OK;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+    uint8_t*& td = E.tab_dev[dev];
+    if (!td) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, E.tab.size()), "hipMalloc plane table");
+        td = static_cast<uint8_t*>(p);
+        HIP_TRY(hipMemcpy(td, E.tab.data(), E.tab.size(), hipMemcpyHostToDevice), "hipMemcpy plane table");
+    }
+    *out = td;
+    return LRM_OK;
+}
 #ifndef LRM_TOLGRID_MIN_POINTS
 #define LRM_TOLGRID_MIN_POINTS 500000 // below: staging the table in every workgroup's LDS costs more than it saves
 #endif
@@ -148,11 +184,16 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
             return LRM_OK;
         }
         if (TL.tol_ok) {
+            const uint8_t* tab = nullptr;
+            if (tol_tab_wanted(n)) {
+                const int rc = tol_tab_device(E, &tab);
+                if (rc != LRM_OK) return rc;
+            }
             uint32_t* w = nullptr;
-            const int rc = tol_workspace(lrm_tol_queue_words(n), stream, &w);
+            const int rc = tol_workspace(tab ? lrm_tol_tab_queue_words(n) : lrm_tol_queue_words(n), stream, &w);
             if (rc != LRM_OK) return rc;
-            HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, (hipStream_t)stream),
-                    "tolerance-mode launch");
+            if (tab) HIP_TRY(lrm_launch_dist_tab(op, x, y, z, n, L, TL, tab, mask, bits, dx, dy, dz, w, (hipStream_t)stream), "tolerance-mode (table) launch");
+            else HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, (hipStream_t)stream), "tolerance-mode launch");
             return LRM_OK;
         }
     }
@@ -165,12 +206,19 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
 int launch_dist_aos_mode(int op, const float* xyz, size_t n, const LrmLegDimensions& leg, const float* quat, const LrmCompiledLeg& L,
                          uint8_t* mask, float* dxyz, void* stream) {
     if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xc0000000ull) {
-        const LrmTolLeg& TL = tol_entry(leg, quat, L).tl;
+        TolEntry& E = tol_entry(leg, quat, L);
+        const LrmTolLeg& TL = E.tl;
         if (TL.tol_ok) {
+            const uint8_t* tab = nullptr;
+            if (tol_tab_wanted(n)) {
+                const int rc = tol_tab_device(E, &tab);
+                if (rc != LRM_OK) return rc;
+            }
             uint32_t* w = nullptr;
-            const int rc = tol_workspace(lrm_tol_queue_words(n), stream, &w);
+            const int rc = tol_workspace(tab ? lrm_tol_tab_queue_words(n) : lrm_tol_queue_words(n), stream, &w);
             if (rc != LRM_OK) return rc;
-            HIP_TRY(lrm_launch_dist_tol_aos(op, xyz, n, L, TL, mask, dxyz, w, (hipStream_t)stream), "tolerance-mode launch");
+            if (tab) HIP_TRY(lrm_launch_dist_tab_aos(op, xyz, n, L, TL, tab, mask, dxyz, w, (hipStream_t)stream), "tolerance-mode (table) launch");
+            else HIP_TRY(lrm_launch_dist_tol_aos(op, xyz, n, L, TL, mask, dxyz, w, (hipStream_t)stream), "tolerance-mode launch");
             return LRM_OK;
         }
     }
@@ -786,6 +834,38 @@ int lrm_dbg_tolgrid_host(const float* xyz, size_t n, const LrmLegDimensions* leg
     }
     return LRM_OK;
 }
+// as lrm_dbg_tol_host with the plane table with deferred decisions (lrm_toltab.cpp) in place of the full plane evaluation;
+// doubt bit 0x100 = a cell without an answer.  stats_out[4] (optional): rows, validity rows, refined cells, table bytes
+int lrm_dbg_toltab_host(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
+                        float* dxyz_out, uint32_t* doubt_out, uint32_t* stats_out) {
+    if (!leg || (n && (!xyz || !mask_out || !dxyz_out || !doubt_out))) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    LrmTolLeg TL;
+    lrm_compile_tol(L, &TL);
+    if (!TL.tol_ok) return fail(LRM_EINVAL, "leg not eligible for the tolerance mode");
+    std::vector<uint8_t> tab;
+    if (!lrm_build_tol_tab(TL, &tab)) return fail(LRM_EINVAL, "leg needs more table rows than a cell code can name");
+    const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab.data());
+    const uint16_t* coarse = reinterpret_cast<const uint16_t*>(tab.data() + sizeof(LrmTolTabHeader));
+    const LrmTolTabView G{hd->rows, hd->vrows, coarse, coarse + (size_t)LRM_TT_N * LRM_TT_N, hd->band_max};
+    if (stats_out) {
+        stats_out[0] = hd->n_rows;
+        stats_out[1] = hd->n_vrows;
+        stats_out[2] = hd->n_fine;
+        stats_out[3] = (uint32_t)tab.size();
+    }
+    for (size_t i = 0; i < n; i++) {
+        LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        uint32_t doubt = 0;
+        mask_out[i] = lrm_dist_toltab(TL, G, p, doubt);
+        dxyz_out[3 * i] = p.x;
+        dxyz_out[3 * i + 1] = p.y;
+        dxyz_out[3 * i + 2] = p.z;
+        doubt_out[i] = doubt;
+    }
+    return LRM_OK;
+}
 // After a plane-table call in LRM_MODE_TOL (synchronises the device): how many points went to the full evaluation
 // (queue A) and how many of those on to the bit-exact code (queue B).
 int lrm_dbg_tol_queue_counts(uint64_t* n_points, uint64_t* n_full, uint64_t* n_exact) {
@@ -962,6 +1042,229 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
     HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
     total_ms += e;
     if (ms) *ms = total_ms;
+    return LRM_OK;
+}
+
+} // extern "C"
+
+// =====================================================================================================================
+// Several GPUs behind the apply_kernel boundary (SURVEY.md section 8(b) "lrm_*_multi", 8(e)): ONE process, ONE host
+// thread, ndev devices.  The reference has no such entry (several_leg.cu:800 uses device 0).  The cloud is cut into the
+// 64-point-aligned contiguous shards of lrm_shard_bounds -- the same arithmetic as lrm_amd/shard.py, so that a
+// torch.distributed run and this call own identical slices -- each device gets one stream, its slice of the input,
+// the fused kernels of the current mode, and packs its reach bytes into ballot words; the words are then all-gathered
+// over xGMI with RCCL's C API (ncclCommInitAll once per device set, one grouped ncclAllGather per call), so that every
+// device ends up with the bit-packed reach mask of the WHOLE cloud (the exchange step of BASELINE config 4), and the
+// per-shard bytes / vectors go back to the caller's arrays.  librccl.so is opened on first use with more than one
+// device (or when LRM_MULTI_FORCE_RCCL=1 asks for it with one): liblrm.so itself keeps depending on HIP alone.
+// =====================================================================================================================
+#include <dlfcn.h>
+
+namespace {
+
+__global__ void pack_mask_bits_kernel(const uint8_t* __restrict__ mask, size_t n, uint64_t* __restrict__ words, size_t nwords) {
+    // one wave per word: lane i reads byte 64 w + i; words beyond ceil(n / 64) (the shard's padding) become 0
+    const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= nwords) return;
+    const size_t i = w * 64 + (threadIdx.x & 63);
+    const uint64_t b = __ballot(i < n && mask[i] != 0);
+    if ((threadIdx.x & 63) == 0) words[w] = b;
+}
+
+struct Rccl {
+    void* handle = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load(std::string* why) {
+        if (handle) return true;
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* nm : names)
+            if ((handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!handle) { *why = std::string("dlopen librccl.so: ") + dlerror(); return false; }
+        CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+        AllGather = (decltype(AllGather))dlsym(handle, "ncclAllGather");
+        GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd || !GetErrorString) {
+            *why = "librccl.so lacks an expected symbol";
+            dlclose(handle);
+            handle = nullptr;
+            return false;
+        }
+        return true;
+    }
+} g_rccl;
+constexpr int kNcclUint64 = 5; // ncclUint64, rccl.h
+
+// communicators of the last device set (ncclCommInitAll costs ~0.1-1 s: kept across calls)
+struct MultiComms {
+    std::vector<int> devs;
+    std::vector<void*> comms;
+} g_multi;
+void multi_release() {
+    if (g_rccl.handle)
+        for (void* c : g_multi.comms)
+            if (c) (void)g_rccl.CommDestroy(c);
+    g_multi.comms.clear();
+    g_multi.devs.clear();
+}
+
+struct MultiDev {
+    int dev = 0;
+    size_t lo = 0, hi = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    void *in = nullptr, *mask = nullptr, *out = nullptr, *words = nullptr, *gathered = nullptr;
+};
+struct MultiState { // releases everything on every exit path
+    std::vector<MultiDev> d;
+    int home = 0;
+    ~MultiState() {
+        for (auto& m : d) {
+            if (hipSetDevice(m.dev) != hipSuccess) continue;
+            if (m.st) (void)hipStreamSynchronize(m.st);
+            for (void* p : {m.in, m.mask, m.out, m.words, m.gathered})
+                if (p) (void)hipFree(p);
+            if (m.a) (void)hipEventDestroy(m.a);
+            if (m.b) (void)hipEventDestroy(m.b);
+            if (m.st) (void)hipStreamDestroy(m.st);
+        }
+        (void)hipSetDevice(home);
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+// shard r of n items over `world` owners: [lo, hi), boundaries multiples of `align` (64: no ballot word straddles two
+// owners); ceil(n / world) rounded up to `align` per owner, the last ones may be short or empty.  = shard.shard_bounds
+int lrm_shard_bounds(size_t n, int world, int rank, size_t align, size_t* lo_out, size_t* hi_out) {
+    if (world < 1 || rank < 0 || rank >= world || align == 0 || !lo_out || !hi_out) return fail(LRM_EINVAL, "bad shard arguments");
+    size_t per = (n + (size_t)world - 1) / (size_t)world;
+    per = (per + align - 1) / align * align;
+    const size_t lo = std::min(n, (size_t)rank * per);
+    *lo_out = lo;
+    *hi_out = std::min(n, lo + per);
+    return LRM_OK;
+}
+
+void lrm_multi_release(void) { multi_release(); }
+
+// apply_kernel (cross_compiled.cu:33-79) for the fused kernel over `ndev` devices.  devices: ordinals, or NULL = 0 .. ndev-1.
+// mask_out[n], dxyz_out[3n]: as lrm_reach_dist.  bits_out: NULL, or ceil(n / 64) words = the gathered bit-packed mask as
+// device devices[0] holds it after the exchange.  ms_per_dev: NULL or [ndev], each device's kernel milliseconds (HIP events
+// on its stream around its launches; 0 for an empty shard).
+int lrm_reach_dist_multi(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, int ndev, const int* devices,
+                         uint8_t* mask_out, float* dxyz_out, uint64_t* bits_out, float* ms_per_dev) {
+    if (!leg || (n && (!xyz || !mask_out || !dxyz_out))) return fail(LRM_EINVAL, "null argument");
+    if (ndev < 1 || ndev > 64) return fail(LRM_EINVAL, "ndev must be 1 .. 64");
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have == 0) return fail(LRM_ENODEV, "no HIP device");
+    std::vector<int> devs(ndev);
+    for (int d = 0; d < ndev; d++) {
+        devs[d] = devices ? devices[d] : d;
+        if (devs[d] < 0 || devs[d] >= have) return fail(LRM_EINVAL, "device ordinal out of range");
+        for (int e = 0; e < d; e++)
+            if (devs[e] == devs[d]) return fail(LRM_EINVAL, "a device is listed twice");
+    }
+    const char* force = std::getenv("LRM_MULTI_FORCE_RCCL");
+    const bool use_rccl = ndev > 1 || (force && force[0] == '1');
+    if (use_rccl) {
+        std::string why;
+        if (!g_rccl.load(&why)) return fail(LRM_ENODEV, why.c_str());
+        if (g_multi.devs != devs) {
+            multi_release();
+            g_multi.comms.assign(ndev, nullptr);
+            const int rc = g_rccl.CommInitAll(g_multi.comms.data(), ndev, devs.data());
+            if (rc != 0) {
+                g_multi.comms.clear();
+                return fail(LRM_ENODEV, (std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc)).c_str());
+            }
+            g_multi.devs = devs;
+        }
+    }
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    MultiState S;
+    (void)hipGetDevice(&S.home);
+    S.d.resize(ndev);
+    size_t lo0 = 0, per = 0;
+    lrm_shard_bounds(n, ndev, 0, 64, &lo0, &per); // shard 0 has the common size (or n, when n is smaller)
+    size_t common = (n + (size_t)ndev - 1) / (size_t)ndev;
+    common = (common + 63) / 64 * 64;
+    const size_t per_words = std::max<size_t>(common / 64, 1);
+    // 1. per device: stream, buffers, input slice on its way, kernels, bit words
+    for (int d = 0; d < ndev; d++) {
+        MultiDev& m = S.d[d];
+        m.dev = devs[d];
+        lrm_shard_bounds(n, ndev, d, 64, &m.lo, &m.hi);
+        const size_t cnt = m.hi - m.lo;
+        HIP_TRY(hipSetDevice(m.dev), "hipSetDevice");
+        HIP_TRY(hipStreamCreateWithFlags(&m.st, hipStreamNonBlocking), "hipStreamCreate");
+        HIP_TRY(hipEventCreate(&m.a), "hipEventCreate");
+        HIP_TRY(hipEventCreate(&m.b), "hipEventCreate");
+        HIP_TRY(hipMalloc(&m.in, std::max<size_t>(cnt, 1) * 3 * sizeof(float)), "hipMalloc shard input");
+        HIP_TRY(hipMalloc(&m.mask, std::max<size_t>(cnt, 1)), "hipMalloc shard mask");
+        HIP_TRY(hipMalloc(&m.out, std::max<size_t>(cnt, 1) * 3 * sizeof(float)), "hipMalloc shard output");
+        HIP_TRY(hipMalloc(&m.words, per_words * sizeof(uint64_t)), "hipMalloc shard words");
+        HIP_TRY(hipMalloc(&m.gathered, per_words * (size_t)ndev * sizeof(uint64_t)), "hipMalloc gathered words");
+        if (cnt) HIP_TRY(hipMemcpyAsync(m.in, xyz + 3 * m.lo, cnt * 3 * sizeof(float), hipMemcpyHostToDevice, m.st), "hipMemcpyAsync shard input");
+        HIP_TRY(hipEventRecord(m.a, m.st), "hipEventRecord");
+        if (cnt) {
+            const int rc = launch_dist_aos_mode(2, static_cast<const float*>(m.in), cnt, *leg, quat_or_default(quat), L,
+                                                static_cast<uint8_t*>(m.mask), static_cast<float*>(m.out), m.st);
+            if (rc != LRM_OK) return rc;
+        }
+        HIP_TRY(hipEventRecord(m.b, m.st), "hipEventRecord");
+        const unsigned pblocks = (unsigned)((per_words * 64 + 255) / 256);
+        hipLaunchKernelGGL(pack_mask_bits_kernel, dim3(pblocks), dim3(256), 0, m.st, static_cast<const uint8_t*>(m.mask), cnt,
+                           static_cast<uint64_t*>(m.words), per_words);
+        HIP_TRY(hipGetLastError(), "pack_mask_bits_kernel");
+    }
+    // 2. the exchange: every device receives every shard's words (grouped: one collective over all communicators)
+    if (use_rccl) {
+        int rc = g_rccl.GroupStart();
+        for (int d = 0; d < ndev && rc == 0; d++) {
+            MultiDev& m = S.d[d];
+            HIP_TRY(hipSetDevice(m.dev), "hipSetDevice");
+            rc = g_rccl.AllGather(m.words, m.gathered, per_words, kNcclUint64, g_multi.comms[d], m.st);
+        }
+        const int rc2 = g_rccl.GroupEnd();
+        if (rc != 0 || rc2 != 0) return fail(LRM_ENODEV, (std::string("ncclAllGather: ") + g_rccl.GetErrorString(rc ? rc : rc2)).c_str());
+    } else {
+        MultiDev& m = S.d[0];
+        HIP_TRY(hipSetDevice(m.dev), "hipSetDevice");
+        HIP_TRY(hipMemcpyAsync(m.gathered, m.words, per_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, m.st), "hipMemcpyAsync words");
+    }
+    // 3. results back: each device's slice of the bytes and vectors, the gathered words from the first device
+    for (int d = 0; d < ndev; d++) {
+        MultiDev& m = S.d[d];
+        const size_t cnt = m.hi - m.lo;
+        HIP_TRY(hipSetDevice(m.dev), "hipSetDevice");
+        if (cnt) {
+            HIP_TRY(hipMemcpyAsync(mask_out + m.lo, m.mask, cnt, hipMemcpyDeviceToHost, m.st), "hipMemcpyAsync shard mask");
+            HIP_TRY(hipMemcpyAsync(dxyz_out + 3 * m.lo, m.out, cnt * 3 * sizeof(float), hipMemcpyDeviceToHost, m.st), "hipMemcpyAsync shard output");
+        }
+        if (d == 0 && bits_out && n)
+            HIP_TRY(hipMemcpyAsync(bits_out, m.gathered, (n + 63) / 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, m.st), "hipMemcpyAsync gathered words");
+    }
+    for (int d = 0; d < ndev; d++) {
+        MultiDev& m = S.d[d];
+        HIP_TRY(hipSetDevice(m.dev), "hipSetDevice");
+        HIP_TRY(hipStreamSynchronize(m.st), "hipStreamSynchronize");
+        float e = 0.f;
+        HIP_TRY(hipEventElapsedTime(&e, m.a, m.b), "hipEventElapsedTime");
+        if (ms_per_dev) ms_per_dev[d] = (m.hi > m.lo) ? e : 0.f;
+    }
+    (void)per;
+    (void)lo0;
     return LRM_OK;
 }
 

@@ -29,5 +29,9 @@ void lrm_compile_tol(const LrmCompiledLeg& L, LrmTolLeg* out);
 // for an eligible leg; at most max_fine coarse cells are refined.  Returns n_fine.
 size_t lrm_build_tol_grid(const LrmTolLeg& L, size_t max_fine, std::vector<uint8_t>* out);
 
+// The plane table with deferred decisions (lrm_types.h: LrmTolTabHeader | uint16 coarse[LRM_TT_N^2] | uint16 fine[16 (n_fine + 1)]).
+// false: the leg needs more distinct rows than a cell code can name -- the caller uses the kernels without a table.
+bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out);
+
 // order[k] = index of the k-th point of the AoS cloud along a Morton (Z) curve over its bounding box (lrm_capi.cpp)
 void lrm_host_morton_order(const float* xyz_aos, size_t n, std::vector<size_t>* order);

@@ -19,6 +19,13 @@ hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const Lrm
 hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz,
                                uint32_t* workspace, hipStream_t st);
+// Table variant (dist_tab_kernel + the same fix-up): tab_dev = device copy of lrm_build_tol_tab's table for TL.
+size_t lrm_tol_tab_queue_words(size_t n);
+hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
+                               const LrmTolLeg& TL, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
+                               float* dz, uint32_t* workspace, hipStream_t st);
+hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const uint8_t* tab_dev,
+                                   uint8_t* mask, float* dxyz, uint32_t* workspace, hipStream_t st);
 // Plane-table variant of LRM_MODE_TOL (three launches on `st`).  grid_dev: device copy of the table built by
 // lrm_build_tol_grid (grid_bytes bytes).  lrm_tolgrid_plan gives the launch geometry and the uint32 words of
 // device workspace the call needs (rewritten by every call).

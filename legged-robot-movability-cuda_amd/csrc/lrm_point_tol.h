@@ -281,6 +281,72 @@ struct LrmTolPlaneGrid {
     }
 };
 
+// ---- plane table with deferred decisions (lrm_types.h LrmTolTabHeader, lrm_toltab.cpp) ----
+struct LrmTolTabView {
+    const LrmTabRow* rows;   // [32]
+    const LrmTabVRow* vrows; // [32]
+    const uint16_t* coarse;  // [LRM_TT_N * LRM_TT_N]
+    const uint16_t* fine;    // [LRM_TT_SUB^2 * (n_fine + 1)]
+    float band_max;
+};
+// code of the cell of plane point (x = abscissa - coxa_length, z), or LRM_TT_UNANSWERED.  Branch-free: every lane
+// reads one coarse entry and one fine entry.
+LRM_HD uint32_t lrm_toltab_lookup(const LrmTolTabView G, float x, float z) {
+    const float fx = __builtin_fmaf(x, 1.0f / LRM_TT_H, LRM_TT_HALF / LRM_TT_H), fz = __builtin_fmaf(z, 1.0f / LRM_TT_H, LRM_TT_HALF / LRM_TT_H);
+    // inside [0, N): also false for nan
+    const bool inside = (fx >= 0.f) && (fx < (float)LRM_TT_N) && (fz >= 0.f) && (fz < (float)LRM_TT_N);
+    const int ix = inside ? (int)fx : 0, iz = inside ? (int)fz : 0;
+    const uint32_t c = G.coarse[iz * LRM_TT_N + ix];
+    const int sx = (int)((fx - (float)ix) * (float)LRM_TT_SUB) & (LRM_TT_SUB - 1), sz = (int)((fz - (float)iz) * (float)LRM_TT_SUB) & (LRM_TT_SUB - 1);
+    const bool refined = (c & 0x8000u) != 0u;
+    const uint32_t f = G.fine[refined ? ((c & 0x7fffu) * (uint32_t)(LRM_TT_SUB * LRM_TT_SUB) + (uint32_t)(sz * LRM_TT_SUB + sx)) : 0u];
+    const uint32_t code = refined ? f : c;
+    return inside ? code : (uint32_t)LRM_TT_UNANSWERED;
+}
+// lrm_tol_plane restricted to what the cell's code names: at most two clamp targets, one circle's point validity.
+// Same arithmetic as lrm_tol_plane on those operands: for a point that no doubt bit sends to the bit-exact code the
+// result (du, dz, valid) is the one lrm_tol_plane gives.
+LRM_HD void lrm_tol_plane_tab(const LrmTolLeg& L, const LrmTolTabView G, uint32_t code, float u, float z, float band, float tau,
+                              float& du, float& dz, bool& valid, uint32_t& doubt) {
+    const float x = u - L.coxa_length;
+    const LrmTabVRow vr = G.vrows[(code >> 10) & 31u];
+    const LrmTabRow ra = G.rows[code & 31u], rb = G.rows[(code >> 5) & 31u];
+    float vacc;
+    {
+        const float vx = x - vr.x, vy = z - vr.y;
+        vacc = __builtin_fmaf(__builtin_fmaf(vy, vy, vx * vx), vr.gs, vr.c);
+    }
+    valid = vacc < 0.f;
+    const float cpen = valid ? 1.0f : 0.0f; // a corner point only competes when the point is invalid (one_leg.cu:109-116)
+    const float ax = x - ra.x, ay = z - ra.y, bx = x - rb.x, by = z - rb.y;
+    const float ma = __builtin_fmaf(ay, ay, ax * ax), mb = __builtin_fmaf(by, by, bx * bx);
+    const float rsa = LRM_FAST_RSQ(ma), rsb = LRM_FAST_RSQ(mb);
+    const float maga = ma * rsa, magb = mb * rsb;
+    const float da = ra.r - maga, db = rb.r - magb;
+    const float wa = __builtin_fmaf(-ra.chw, maga, __builtin_fmaf(ax, ra.mx, ay * ra.my));
+    const float wb = __builtin_fmaf(-rb.chw, magb, __builtin_fmaf(bx, rb.mx, by * rb.my));
+    const float cacc = fminf(__builtin_fmaf(-ra.bw, maga, fabsf(wa)), __builtin_fmaf(-rb.bw, magb, fabsf(wb)));
+    // an invalid clamp ranks as +huge, and so does a corner point next to a valid point
+    const float ka = fmaxf(fmaxf(da * da, wa * -1.0e30f), ra.corner * cpen);
+    const float kb = fmaxf(fmaxf(db * db, wb * -1.0e30f), rb.corner * cpen);
+    const bool wina = ka <= kb;
+    const float lo2 = wina ? ka : kb, hi2 = wina ? kb : ka;
+    // |b - a| < tau  <=>  b^2 < a^2 + tau (2a + tau), with the relative allowance of lrm_tol_plane's ranking keys
+    const float a = LRM_FAST_SQRT(lo2);
+    const float tie_thr = __builtin_fmaf(lo2, 4.0e-6f, __builtin_fmaf(tau, __builtin_fmaf(2.0f, a, tau), lo2));
+    const float vx = wina ? ax : bx, vy = wina ? ay : by, m = wina ? ma : mb, rs = wina ? rsa : rsb, r = wina ? ra.r : rb.r;
+    const float s = __builtin_fmaf(-r, rs, 1.0f);
+    du = vx * s;
+    dz = vy * s;
+    uint32_t lu = 0;
+    lu |= !(fabsf(vacc) > band) ? LRM_TD_REGION : 0u;
+    lu |= !(cacc > tau) ? LRM_TD_CLAMP : 0u;
+    lu |= !(hi2 > tie_thr) ? LRM_TD_TIE : 0u;
+    lu |= (!(lo2 < 1.0e30f) || !(m * LRM_TOL_AMP2 > r * r)) ? LRM_TD_NONE : 0u;
+    lu |= (code == (uint32_t)LRM_TT_UNANSWERED || !(band <= G.band_max)) ? LRM_TD_AMBIG : 0u;
+    doubt |= lu;
+}
+
 // distance_global + reachability_global (one_leg_global.cu:74-130) of one body-frame point.
 // p: in = the point, out = the distance vector.  Returns the reach / validity flag (the two coincide whenever
 // no decision is in doubt, see lrm_reach_from_dist).  doubt != 0: the outputs must not be used.
@@ -574,6 +640,23 @@ LRM_HD bool lrm_dist_tol(const LrmTolLeg& L, const LrmTolTables T, LrmVec3& p, u
 #if !defined(__HIP_DEVICE_COMPILE__)
     if (need) lu |= LRM_TD_SECOND; // statistic
 #endif
+    doubt |= lu;
+    return lrm_tol_finish(L, S, A, need, B, p, doubt);
+}
+// the staged evaluation with the plane table (deferred decisions) in place of lrm_tol_plane
+LRM_HD bool lrm_dist_toltab(const LrmTolLeg& L, const LrmTolTabView G, LrmVec3& p, uint32_t& doubt) {
+    const LrmTolPoint S = lrm_tol_prologue(L, p);
+    uint32_t lu = S.lu;
+    float du, dz;
+    bool valid;
+    lrm_tol_plane_tab(L, G, lrm_toltab_lookup(G, S.u0 - L.coxa_length, S.z), S.u0, S.z, S.band, S.tau, du, dz, valid, lu);
+    const LrmTolCand A = lrm_tol_candidate(S, false, du, dz, valid, lu);
+    LrmTolCand B = A;
+    const bool need = lrm_tol_need_second(L, S, A);
+    if (need) {
+        lrm_tol_plane_tab(L, G, lrm_toltab_lookup(G, S.u1 - L.coxa_length, S.z), S.u1, S.z, S.band, S.tau, du, dz, valid, lu);
+        B = lrm_tol_candidate(S, true, du, dz, valid, lu);
+    }
     doubt |= lu;
     return lrm_tol_finish(L, S, A, need, B, p, doubt);
 }

@@ -353,6 +353,121 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Table variant (LrmTolTabHeader, lrm_toltab.cpp): the plane evaluation of a yaw candidate is ONE look-up in the
+// plane table with deferred decisions plus the reduced evaluation of what the cell names (lrm_tol_plane_tab: two
+// clamp targets, one circle's validity).  That is short enough to run both candidates in the owning lane: no
+// workgroup stage, no barriers in the loop, no LDS task arrays.  A point whose cell carries no answer (0.6 % of the
+// config-2 cloud) is queued with the doubtful ones for the bit-exact fix-up.  The table (43 KB for the M2 leg: 32 KB
+// coarse + 32 B per refined cell) stays in global memory: it is read by every workgroup of every launch and lives in
+// the L2; its rows (1.5 KB) are staged in LDS.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef LRM_TAB_MIN_WAVES
+#define LRM_TAB_MIN_WAVES 8
+#endif
+#ifndef LRM_TAB_GRID_MULT
+#define LRM_TAB_GRID_MULT 8
+#endif
+struct TabLds {
+    LrmTabRow rows[32];
+    LrmTabVRow vrows[32];
+};
+template <int kOp, bool kAoS = false>
+__global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
+    const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
+    float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ tab, uint32_t* __restrict__ queue,
+    uint32_t* __restrict__ counts) {
+    __shared__ TabLds s_tab;
+    __shared__ uint32_t s_qn;
+    const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
+    const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
+    LrmVec3 p_next{0.f, 0.f, 0.f};
+    {
+        const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x;
+        const size_t rb0 = (size_t)blockIdx.x * kBlock;
+        const uint32_t to = lrm_opaque(threadIdx.x * 4u);
+        if (i0 < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb0, 3u * to), lrm_at(x + 3 * rb0, 3u * to + 4u), lrm_at(x + 3 * rb0, 3u * to + 8u)}
+                                  : LrmVec3{lrm_at(x + rb0, to), lrm_at(y + rb0, to), lrm_at(z + rb0, to)};
+    }
+    {
+        static_assert(sizeof(TabLds) == sizeof(hd->rows) + sizeof(hd->vrows) && sizeof(TabLds) % 16 == 0, "rows | vrows");
+        const uint4* src = reinterpret_cast<const uint4*>(&hd->rows[0]);
+        for (int i = threadIdx.x; i < (int)(sizeof(TabLds) / 16); i += kBlock) reinterpret_cast<uint4*>(&s_tab)[i] = src[i];
+        if (threadIdx.x == 0) s_qn = 0;
+        __syncthreads();
+    }
+    const uint16_t* coarse = reinterpret_cast<const uint16_t*>(tab + sizeof(LrmTolTabHeader));
+    const LrmTolTabView G{s_tab.rows, s_tab.vrows, coarse, coarse + (size_t)LRM_TT_N * LRM_TT_N, hd->band_max};
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t n_pad = (uint32_t)((n + 63) & ~(size_t)63); // whole waves iterate together (ballots below)
+    uint32_t* seg = queue + (size_t)blockIdx.x * kSegCap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t toff0 = threadIdx.x * 4u;
+    uint32_t round = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride, round++) {
+        const bool live = i < n;
+        const size_t rbase = (size_t)blockIdx.x * kBlock + (size_t)round * stride;
+        const uint32_t toff = lrm_opaque(toff0), tid_o = lrm_opaque(threadIdx.x);
+        LrmVec3 p = p_next;
+        const LrmTolPoint S = lrm_tol_prologue(L, p);
+        // both cells first: the two look-ups (two dependent loads each) are in flight together
+        const uint32_t code0 = lrm_toltab_lookup(G, S.u0 - L.coxa_length, S.z);
+        const uint32_t code1 = lrm_toltab_lookup(G, S.u1 - L.coxa_length, S.z);
+        {
+            const uint32_t i_next = i + stride;
+            const size_t rb_next = rbase + stride;
+            p_next = LrmVec3{0.f, 0.f, 0.f};
+            if (i_next < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
+                                          : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
+        }
+        uint32_t lu = S.lu;
+        float du, dzz;
+        bool valid;
+        lrm_tol_plane_tab(L, G, code0, S.u0, S.z, S.band, S.tau, du, dzz, valid, lu);
+        const LrmTolCand A = lrm_tol_candidate(S, false, du, dzz, valid, lu);
+        const bool need = live && lrm_tol_need_second(L, S, A);
+        LrmTolCand B = A;
+        if (__any(need)) { // a random cloud: always; a sorted one: a quarter of its waves
+            uint32_t bd = 0;
+            lrm_tol_plane_tab(L, G, code1, S.u1, S.z, S.band, S.tau, du, dzz, valid, bd);
+            B = lrm_tol_candidate(S, true, du, dzz, valid, bd);
+            lu |= need ? bd : 0u;
+        }
+        uint32_t doubt = lu;
+        const bool m = lrm_tol_finish(L, S, A, need, B, p, doubt) && live;
+        doubt = live ? (doubt & 0xffffu) : 0u;
+        if (live) {
+            if (kAoS) {
+                lrm_at(dx + 3 * rbase, 3u * toff) = p.x;
+                lrm_at(dx + 3 * rbase, 3u * toff + 4u) = p.y;
+                lrm_at(dx + 3 * rbase, 3u * toff + 8u) = p.z;
+            } else {
+                lrm_at(dx + rbase, toff) = p.x;
+                lrm_at(dy + rbase, toff) = p.y;
+                lrm_at(dz + rbase, toff) = p.z;
+            }
+            if (mask) lrm_at(mask + rbase, tid_o) = m;
+        }
+        if (bits) {
+            const uint64_t w = __ballot(m);
+            if (lane == 0) lrm_at(bits + (rbase >> 6), lrm_opaque((uint32_t)wave * 8u)) = w;
+        }
+        const uint64_t dm = __ballot(doubt != 0);
+        if (dm) {
+            uint32_t qb = 0;
+            if (lane == 0) qb = atomicAdd(&s_qn, (uint32_t)__popcll(dm));
+            qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+            if (doubt) {
+                const uint32_t qs = qb + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+                if (qs < (uint32_t)kSegCap) seg[qs] = i;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
+}
+
 // Bit i of the ballot words an earlier launch wrote becomes `m`.  Only this lane ever changes that bit, so a plain
 // read decides whether anything has to change; the (rare) change is an atomic on the word, which other lanes patch
 // other bits of.  (Unconditional atomics cost the middle kernel 40 us per 7e5 points.)
@@ -752,6 +867,48 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
     const size_t stride = blocks * kBlock;
     if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
     else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    return hipGetLastError();
+}
+
+// Table variant: tab_dev = the device copy of lrm_build_tol_tab's table for TL.  Same workspace layout and fix-up as above.
+static size_t tab_main_blocks(size_t n) {
+    const size_t base = (size_t)256 * LRM_TAB_MIN_WAVES * LRM_TAB_GRID_MULT; // workgroups of four waves: every resident slot LRM_TAB_GRID_MULT times over
+    const size_t need = (n + kBlock - 1) / kBlock;
+    size_t blocks = std::max(base, (need + 2) / 3);
+    if (blocks > need) blocks = need;
+    if (blocks == 0) blocks = 1;
+    return blocks;
+}
+size_t lrm_tol_tab_queue_words(size_t n) { return tab_main_blocks(n) * (kSegCap + 1); }
+hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
+                               const LrmTolLeg& TL, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
+                               float* dz, uint32_t* workspace /* lrm_tol_tab_queue_words(n) uint32 */, hipStream_t st) {
+    const size_t blocks = tab_main_blocks(n);
+    uint32_t* counts = workspace;
+    uint32_t* queue = workspace + blocks;
+    if (op == 2) hipLaunchKernelGGL(dist_tab_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts);
+    else hipLaunchKernelGGL(dist_tab_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
+    const size_t stride = blocks * kBlock;
+    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    return hipGetLastError();
+}
+hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const uint8_t* tab_dev,
+                                   uint8_t* mask, float* dxyz, uint32_t* workspace, hipStream_t st) {
+    const size_t blocks = tab_main_blocks(n);
+    uint32_t* counts = workspace;
+    uint32_t* queue = workspace + blocks;
+    if (op == 2) hipLaunchKernelGGL((dist_tab_kernel<2, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, tab_dev, queue, counts);
+    else hipLaunchKernelGGL((dist_tab_kernel<1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, tab_dev, queue, counts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
+    const size_t stride = blocks * kBlock;
+    if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
     return hipGetLastError();
 }
 

@@ -182,3 +182,42 @@ struct LrmTolGridHeader {
     float band_max;       // the table holds for points whose decision band (mm) is at most this
     uint32_t pad[2];
 };
+
+// ---- plane table with deferred decisions (lrm_toltab.cpp; lrm_point_tol.h: lrm_tol_plane_tab) -------------------
+// Second generation of the table above.  A cell no longer has to carry ONE answer: it names up to two clamp targets
+// that can win anywhere in the cell and the one circle (if any) whose point validity is open over the cell; the
+// per-point code evaluates just those (a "reduced" lrm_tol_plane: same arithmetic on fewer operands, so the winner's
+// vector is the same float for float).  Everything else -- the region, the other circles' validity, the other clamp
+// targets, the arc tests of targets that are valid all over the cell -- is decided per cell on the host with
+// Lipschitz bounds.  With 16 mm cells refined once to 4 mm, 99.3 % of the plane evaluations of the config-2 cloud
+// are answered (the first-generation table: 92.8 %); the rest go to the bit-exact fix-up like any doubtful point.
+//   layout: LrmTolTabHeader | uint16 coarse[LRM_TT_N^2] | uint16 fine[LRM_TT_SUB^2 * (n_fine + 1)]
+//   coarse: bit 15 set (and not LRM_TT_UNANSWERED16): refined, bits 0-14 = fine block;  else a cell code
+//   code (15 bits): target A (row, 5 bits) | target B (row, 5 bits) << 5 | validity row (5 bits) << 10;
+//                   LRM_TT_UNANSWERED = 0x7fff: no answer (rows 31 never exist)
+//   rows[]:  a clamp target {x, y, r, corner | mx, my, chw, bw}: `corner` = 3e38 for a corner point (it only competes when
+//            the point is invalid: one_leg.cu:109-116), 0 for a circle; the arc record as LrmTolLeg::Circle, with
+//            (1, 0, -2, 0) = "valid all over the cell".  Row 0 is NONE (never valid): the B slot of a one-target cell.
+//   vrows[]: point validity v = |p - (x, y)|^2 gs + c (valid <=> v < 0); rows 0 / 1 are the constants false / true.
+#define LRM_TT_N 128
+#define LRM_TT_H 16.0f
+#define LRM_TT_HALF 1024.0f
+#ifndef LRM_TT_SUB
+#define LRM_TT_SUB 16 // sub-cells per axis of a refined cell (1 mm): a fine block is LRM_TT_SUB^2 uint16
+#endif
+#define LRM_TT_UNANSWERED 0x7fffu
+#define LRM_TT_MAX_ROWS 31
+struct alignas(16) LrmTabRow {
+    float x, y, r, corner;
+    float mx, my, chw, bw;
+};
+struct alignas(16) LrmTabVRow {
+    float x, y, gs, c;
+};
+struct LrmTolTabHeader {
+    uint32_t n_fine;   // refined cells (2 LRM_TT_SUB^2 bytes each)
+    float band_max;    // the table holds for points whose decision band (mm) is at most this
+    uint32_t n_rows, n_vrows;
+    LrmTabRow rows[32];
+    LrmTabVRow vrows[32];
+};

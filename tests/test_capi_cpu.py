@@ -230,3 +230,31 @@ def test_tolerance_kernels_keep_their_register_budget(lrm):
         assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, name
         assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 8, name
     assert seen == 4  # kOp 1 and 2, SoA and float3 layout
+
+
+def test_shard_bounds_of_the_c_abi_equal_the_python_ones(lrm):
+    """lrm_shard_bounds (the split lrm_reach_dist_multi uses) == lrm_amd.shard.shard_bounds (the torch.distributed
+    drivers): both sides of a mixed deployment own identical slices; shards cover [0, n) and start on whole words."""
+    from lrm_amd import shard
+    for n in (0, 1, 63, 64, 65, 1000, 10**7 + 3, 10**8):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = lrm.c_shard_bounds(n, world, r)
+                assert (lo, hi) == shard.shard_bounds(n, world, r)
+                assert lo == prev or lo == n
+                assert lo % 64 == 0 or lo == n
+                prev = hi
+            assert prev == n
+    with pytest.raises(lrm.LrmError):
+        lrm.c_shard_bounds(10, 2, 2)
+    with pytest.raises(lrm.LrmError):
+        lrm.c_shard_bounds(10, 0, 0)
+
+
+def test_multi_entry_fails_without_a_device(lrm):
+    """no GPU in the build container: the multi-device entry reports LRM_ENODEV, it never computes on the CPU"""
+    if lrm.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(lrm.LrmError):
+        lrm.apply_reach_dist_multi(np.zeros((10, 3), np.float32), lrm.get_M2_leg(0.0), None, ndev=1)
