@@ -199,6 +199,14 @@ int lrm_positionability(const float* bodies_aos, size_t nb, const float* targets
                         const LrmLegDimensions* legs, size_t nlegs, const float* quats,
                         size_t nquat, int reference_culls, uint8_t* body_mask_out, float* ms);
 
+/* lrm_positionability's orientation sweep on clouds that already live on the device (SoA float32), device-resident
+ * masks in and out: no copies of the clouds, no reordering (feed Morton-ordered clouds).  reference_culls: 0 none, 2 the
+ * per-orientation cylinder culls (the caller has applied multi_rot_estimator's one-time culls, several_leg.cu:413-502,
+ * as the sharded drivers do).  active_in (device, may be NULL = every body): bodies with 0 are not tested;
+ * accepted_out[nb] (device).  Null stream; returns when the device has finished; *ms = the sweep's kernel time. */
+int lrm_positionability_dev(const float* bx, const float* by, const float* bz, size_t nb, const float* tx, const float* ty,
+                            const float* tz, size_t nt, const LrmLegDimensions* legs, size_t nlegs, const float* quats,
+                            size_t nquat, int reference_culls, const uint8_t* active_in, uint8_t* accepted_out, float* ms);
 /* Morton (Z-curve) order of a host cloud: order_out[k] = index of the k-th point along the curve.
  * The pair kernels (lrm_reach_any_dev, lrm_any_in_*_dev) skip whole 1024-target tiles by bounding
  * box; feeding them clouds (and centres / bodies) in this order makes the boxes compact in any
@@ -258,6 +266,12 @@ int lrm_apply_oct_dev(const float* fx, const float* fy, const float* fz, size_t 
                       const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out, float* ms,
                       int rank, int world, LrmOctExchange exchange, void* user);
 const char* lrm_octree_last_error(void);
+/* Trace of the octree calls of this thread (tests): after lrm_dbg_oct_trace(1) every evaluated child of every level is
+ * recorded as 12 floats {c[3], h[3], parent h[3], flag bits the kernel returned (1 reach, 2 leaf, 4 edge),
+ * parent_valid + 2 * rotations + 4 * skipped, depth}; lrm_dbg_oct_trace_read copies them (out may be NULL to ask for
+ * the count); lrm_dbg_oct_trace(0) stops and clears. */
+int lrm_dbg_oct_trace(int enable);
+int lrm_dbg_oct_trace_read(float* out, size_t capacity_records, size_t* n_out);
 
 /* ---- several GPUs behind the apply_kernel boundary (one process, one host thread) ------------------------------
  * New capability: the reference runs on device 0 only (several_leg.cu:800; apply_kernel cross_compiled.cu:33-79).
@@ -299,18 +313,18 @@ int lrm_dbg_fast_host(const float* xyz_aos, size_t n, const LrmLegDimensions* le
  * outputs are final).  Fails with LRM_EINVAL for a leg the mode does not support. */
 int lrm_dbg_tol_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                      uint8_t* mask_out, float* dxyz_aos_out, uint32_t* doubt_out);
-/* As lrm_dbg_tol_host with the mode's plane table (csrc/lrm_tolgrid.cpp) in place of the full plane evaluation:
- * doubt bit 0x100 = the table holds no answer for a candidate of this point (the GPU path then evaluates the
- * point in full); *n_fine_out (may be NULL) = refined cells of the table. */
-int lrm_dbg_tolgrid_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
-                         uint8_t* mask_out, float* dxyz_aos_out, uint32_t* doubt_out, uint32_t* n_fine_out);
 /* As lrm_dbg_tol_host with the plane table with deferred decisions (csrc/lrm_toltab.cpp) in place of the full plane
  * evaluation; doubt bit 0x100 = a cell without an answer.  stats_out[4] (or NULL): rows, validity rows, refined cells, bytes. */
 int lrm_dbg_toltab_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                         uint8_t* mask_out, float* dxyz_out, uint32_t* doubt_out, uint32_t* stats_out);
-/* After a device call that took the plane-table path of LRM_MODE_TOL (>= 5e5 points): points of that call, how
- * many of them needed the full evaluation, how many the bit-exact code.  Synchronises the device. */
-int lrm_dbg_tol_queue_counts(uint64_t* n_points, uint64_t* n_full, uint64_t* n_exact);
+/* Counting build only (csrc: -DLRM_PAIR_COUNT, tools/c3_evidence.py): what the wave-per-body pair kernel evaluated since the
+ * last call: out[0] full (leg, target) evaluations, [1] leg bounding-sphere tests, [2] footholds inside a body's reach sphere,
+ * [3] footholds loaded.  LRM_EINVAL in an ordinary build. */
+int lrm_dbg_pair_counts(uint64_t out[4]);
+/* After a distance / fused call on device buffers in LRM_MODE_TOL: the points of that call, how many of them its main
+ * kernel queued for the bit-exact fix-up launch, and how many workgroups overflowed their queue segment (all their
+ * points are re-evaluated).  Synchronises that device. */
+int lrm_dbg_tol_queue_counts(uint64_t* n_points, uint64_t* n_queued, uint64_t* n_overflowed);
 /* 1 if (leg, quat) is eligible for LRM_MODE_TOL, else 0 */
 int lrm_dbg_tol_ok(const LrmLegDimensions* leg, const float* quat);
 /* The per-leg bounding sphere the pair kernels use to skip batches of footholds:

@@ -82,9 +82,12 @@ def load():
         "lrm_dbg_tol_host": [vp, sz, vp, vp, vp, vp, vp],
         "lrm_dbg_tol_ok": [vp, vp],
         "lrm_dbg_tol_queue_counts": [vp, vp, vp],
-        "lrm_dbg_tolgrid_host": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_toltab_host": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_shard_bounds": [sz, C.c_int, C.c_int, sz, vp, vp],
+        "lrm_dbg_pair_counts": [vp],
+        "lrm_positionability_dev": [vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, sz, C.c_int, vp, vp, vp],
+        "lrm_dbg_oct_trace": [C.c_int],
+        "lrm_dbg_oct_trace_read": [vp, sz, vp],
         "lrm_reach_dist_multi": [vp, sz, vp, vp, C.c_int, vp, vp, vp, vp, vp],
         "lrm_dbg_pair_sphere": [vp, vp, vp],
         "lrm_dbg_exact_math_host": [vp, vp, sz, vp, vp, vp],
@@ -94,7 +97,12 @@ def load():
         "lrm_any_in_cylinder_dev": [vp, vp, vp, sz, vp, vp, vp, sz, fp, fp, fp, vp, vp],
     }
     for name, argtypes in sig.items():
-        fn = getattr(L, name)
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            if name.startswith("lrm_dbg_"):  # an older library variant in an A/B run (LRM_LIB_PATH): diagnostics may be missing
+                continue
+            raise
         fn.argtypes = argtypes
         fn.restype = C.c_int
     L.lrm_leg_factory.argtypes = [fp] * 11 + [vp]
@@ -399,19 +407,28 @@ def dbg_toltab_host(xyz, leg, quat=None):
     return mask, d, doubt, dict(rows=int(stats[0]), vrows=int(stats[1]), refined=int(stats[2]), bytes=int(stats[3]))
 
 
-def dbg_tolgrid_host(xyz, leg, quat=None):
-    """Tolerance mode through its plane table on the host -> (mask, dist, doubt bits, refined cells)."""
-    xyz = _f32(xyz, (-1, 3))
-    n = len(xyz)
-    mask, d, doubt = np.zeros(n, np.uint8), np.zeros_like(xyz), np.zeros(n, np.uint32)
-    nf = C.c_uint32(0)
-    check(load().lrm_dbg_tolgrid_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d),
-                                      _ptr(doubt), C.addressof(nf)))
-    return mask, d, doubt, int(nf.value)
+def dbg_oct_trace(enable):
+    check(load().lrm_dbg_oct_trace(1 if enable else 0))
+
+
+def dbg_oct_trace_read():
+    """records of the traced octree calls: float32[n, 12] = c[3], h[3], parent h[3], flag bits, parent_valid + 2 rot + 4 skip, depth"""
+    n = C.c_size_t(0)
+    check(load().lrm_dbg_oct_trace_read(None, 0, C.addressof(n)))
+    out = np.zeros((int(n.value), 12), np.float32)
+    check(load().lrm_dbg_oct_trace_read(_ptr(out), int(n.value), C.addressof(n)))
+    return out
+
+
+def dbg_pair_counts():
+    """counting build only: (full evaluations, leg-sphere tests, footholds inside a reach sphere, footholds loaded) since the last call"""
+    out = np.zeros(4, np.uint64)
+    check(load().lrm_dbg_pair_counts(_ptr(out)))
+    return [int(v) for v in out]
 
 
 def dbg_tol_queue_counts():
-    """(points, sent to the full evaluation, sent to the bit-exact code) of the last plane-table call."""
+    """(points, queued for the bit-exact fix-up, overflowed workgroup segments) of the last tolerance-mode call on device buffers"""
     a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     check(load().lrm_dbg_tol_queue_counts(C.addressof(a), C.addressof(b), C.addressof(c)))
     return int(a.value), int(b.value), int(c.value)

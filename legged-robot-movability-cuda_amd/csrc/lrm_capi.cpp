@@ -6,7 +6,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -15,9 +18,6 @@
 #include "lrm_point.h"
 #include "lrm_point_fast.h"
 #include "lrm_point_tol.h"
-#ifndef LRM_TOLGRID_MAX_FINE
-#define LRM_TOLGRID_MAX_FINE 1800 // refined cells at most: 32 KB coarse + 28 KB fine + the circle tables stay under 64 KB of LDS
-#endif
 
 namespace {
 
@@ -50,9 +50,7 @@ struct TolKey {
 };
 struct TolEntry {
     LrmTolLeg tl;
-    std::vector<uint8_t> grid;     // the first-generation plane table (lrm_build_tol_grid), built on first use
-    std::map<int, uint8_t*> dev;   // its device copies, by device ordinal
-    std::vector<uint8_t> tab;      // the plane table with deferred decisions (lrm_build_tol_tab), built on first use
+    std::vector<uint8_t> tab;      // the plane table (lrm_build_tol_tab), built on first use
     int tab_state = 0;             // 0 not built yet, 1 built, -1 this leg has none (too many rows)
     std::map<int, uint8_t*> tab_dev;
 };
@@ -65,16 +63,19 @@ TolEntry& tol_entry(const LrmLegDimensions& leg, const float* quat, const LrmCom
     if (it != g_tol_cache.end()) return it->second;
     if (g_tol_cache.size() >= 64) { // a sweep over many orientations: start over (device copies are released)
         for (auto& e : g_tol_cache)
-        {
-            for (auto& d : e.second.dev) (void)hipFree(d.second);
             for (auto& d : e.second.tab_dev) (void)hipFree(d.second);
-        }
         g_tol_cache.clear();
     }
     TolEntry& e = g_tol_cache[k];
     lrm_compile_tol(L, &e.tl);
     return e;
 }
+// where the last tolerance-mode launch left its per-workgroup doubt counts, for lrm_dbg_tol_queue_counts
+struct TolLast {
+    int dev = -1;
+    const uint32_t* counts = nullptr; // device: one count per workgroup of the main kernel
+    size_t blocks = 0, n = 0;
+} g_tol_last;
 // Device workspace of the doubt queues (rewritten by every call), one per (device, stream) in use, grown on demand.
 struct TolWorkspace {
     uint32_t* p = nullptr;
@@ -86,6 +87,7 @@ int tol_workspace(size_t words, void* stream, uint32_t** out) {
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
     TolWorkspace& w = g_tol_ws[std::make_pair(dev, stream)];
     if (words > w.words) {
+        if (w.p && g_tol_last.counts == w.p) g_tol_last = TolLast{}; // the statistic of the last call goes with its workspace
         if (w.p) (void)hipFree(w.p); // synchronises with whatever still uses it
         w.p = nullptr;
         w.words = 0;
@@ -97,27 +99,6 @@ int tol_workspace(size_t words, void* stream, uint32_t** out) {
     }
     *out = w.p;
     return LRM_OK;
-}
-// geometry of the last plane-table call, for lrm_dbg_tol_queue_counts
-struct TolLast {
-    uint32_t* ws = nullptr;
-    size_t waves = 0, seg_cap = 0, n = 0;
-} g_tol_last;
-#ifndef LRM_TOLGRID_BLOCK
-#define LRM_TOLGRID_BLOCK_DEFAULT 512
-#else
-#define LRM_TOLGRID_BLOCK_DEFAULT LRM_TOLGRID_BLOCK
-#endif
-// The plane-table variant is opt-in (environment LRM_TOL_PLANE_TABLE=1, read once): its table kernel runs at 3.2 TB/s
-// (79 us per 1e7 points against 115 us for the plain tolerance kernel), but the 7 % of points its table cannot
-// answer cost 65 us more wherever they are re-evaluated (scattered 4-byte accesses), so end to end it is slower
-// (DESIGN.md section 3).
-bool tol_plane_table_enabled() {
-    static const bool on = [] {
-        const char* e = std::getenv("LRM_TOL_PLANE_TABLE");
-        return e && e[0] == '1';
-    }();
-    return on;
 }
 // The table kernel (dist_tab_kernel) is the default of LRM_MODE_TOL from LRM_TOLTAB_MIN_POINTS points on (building the
 // table costs a few milliseconds of host geometry per (leg, orientation)); LRM_TOL_TABLE=0 in the environment keeps
@@ -149,10 +130,6 @@ int tol_tab_device(TolEntry& E, const uint8_t** out) {
     *out = td;
     return LRM_OK;
 }
-#ifndef LRM_TOLGRID_MIN_POINTS
-#define LRM_TOLGRID_MIN_POINTS 500000 // below: staging the table in every workgroup's LDS costs more than it saves
-#endif
-
 // distance / fused launch of the SoA kernels in the current mode. op: 1 distance, 2 reach + distance
 int launch_dist_mode(int op, const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions& leg,
                      const float* quat, const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
@@ -160,29 +137,6 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
     if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xc0000000ull) { // 32-bit point indices in the tolerance kernels (n + one grid stride < 2^32)
         TolEntry& E = tol_entry(leg, quat, L);
         const LrmTolLeg& TL = E.tl;
-        if (TL.tol_ok && n >= (size_t)LRM_TOLGRID_MIN_POINTS && tol_plane_table_enabled()) {
-            // plane-table variant: table on the host once per (leg, orientation), one device copy per GPU
-            if (E.grid.empty()) lrm_build_tol_grid(TL, LRM_TOLGRID_MAX_FINE, &E.grid);
-            int dev = 0;
-            HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
-            uint8_t*& gd = E.dev[dev];
-            if (!gd) {
-                void* p = nullptr;
-                HIP_TRY(hipMalloc(&p, E.grid.size()), "hipMalloc plane table");
-                gd = static_cast<uint8_t*>(p);
-                HIP_TRY(hipMemcpy(gd, E.grid.data(), E.grid.size(), hipMemcpyHostToDevice), "hipMemcpy plane table");
-            }
-            uint32_t blocks = 0, seg_cap = 0;
-            size_t words = 0;
-            lrm_tolgrid_plan(n, E.grid.size(), &blocks, &seg_cap, &words);
-            uint32_t* w = nullptr;
-            const int rc = tol_workspace(words, stream, &w);
-            if (rc != LRM_OK) return rc;
-            HIP_TRY(lrm_launch_dist_tolgrid(op, x, y, z, n, L, TL, gd, E.grid.size(), mask, bits, dx, dy, dz, w, (hipStream_t)stream),
-                    "tolerance-mode (plane table) launch");
-            g_tol_last = TolLast{w, (size_t)blocks * (LRM_TOLGRID_BLOCK_DEFAULT / 64), seg_cap, n};
-            return LRM_OK;
-        }
         if (TL.tol_ok) {
             const uint8_t* tab = nullptr;
             if (tol_tab_wanted(n)) {
@@ -194,6 +148,10 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
             if (rc != LRM_OK) return rc;
             if (tab) HIP_TRY(lrm_launch_dist_tab(op, x, y, z, n, L, TL, tab, mask, bits, dx, dy, dz, w, (hipStream_t)stream), "tolerance-mode (table) launch");
             else HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, (hipStream_t)stream), "tolerance-mode launch");
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const size_t words = tab ? lrm_tol_tab_queue_words(n) : lrm_tol_queue_words(n);
+            g_tol_last = TolLast{dev, w, words / (LRM_TOL_SEG_CAP_WORDS + 1), n}; // workspace = counts[blocks] | queue[blocks * cap]
             return LRM_OK;
         }
     }
@@ -244,6 +202,147 @@ struct Events {
     }
 };
 
+// ---- pipelined host boundary (opt-in: LRM_HOST_PIPELINE=1) ---------------------------------------------------------
+// apply_kernel (cross_compiled.cu:41-77) allocates, copies the whole input, runs the kernel, copies the whole output and
+// frees, one after the other; for 1e7 fused points that is 16 ms of which 0.1-0.3 ms are kernels (pageable copies at
+// ~22 GB/s, one direction at a time).  With the pipeline the same call keeps its device buffers and three streams per
+// device, cuts the cloud into chunks (LRM_HOST_PIPELINE_CHUNK points, default 2^20: 12 MB in, 13 MB out) and runs
+//     H2D of chunk c + 1  ||  kernels of chunk c  ||  D2H of chunk c - 1
+// -- the two copy directions use PCIe's two directions at once.  The copies are issued from two helper threads: a
+// copy from / to pageable user memory occupies its calling thread (the runtime stages it through its own pinned
+// buffers), so one thread per direction is what lets them overlap; the caller's thread launches the kernels.
+// Results are the same bytes as without the pipeline (same kernels on sub-ranges; the tolerance mode's fix-up is per
+// launch anyway).  Returned ms = the sum of the chunks' kernel times (HIP events on the compute stream).
+struct HostPipe {
+    hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+    void *d_in = nullptr, *d_mask = nullptr, *d_out = nullptr;
+    size_t cap = 0; // points the device buffers hold
+    std::vector<hipEvent_t> ev_in, ev_k0, ev_k1;
+};
+std::map<int, HostPipe> g_host_pipe; // per device ordinal; lives until lrm_release_workspaces()
+size_t host_pipeline_chunk() {
+    const char* e = std::getenv("LRM_HOST_PIPELINE_CHUNK");
+    const long v = e ? std::atol(e) : 0;
+    return v >= 4096 ? ((size_t)v + 63) & ~(size_t)63 : (size_t)1 << 20;
+}
+bool host_pipeline_enabled() {
+    const char* e = std::getenv("LRM_HOST_PIPELINE");
+    return e && e[0] == '1';
+}
+int host_apply_pipelined(int op, const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat,
+                         uint8_t* mask_out, float* dxyz_out, float* ms, const LrmCompiledLeg& L) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+    HostPipe& P = g_host_pipe[dev];
+    const bool want_mask = (op != 1) || mask_out;
+    if (!P.s_in) {
+        HIP_TRY(hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking), "hipStreamCreate");
+        HIP_TRY(hipStreamCreateWithFlags(&P.s_k, hipStreamNonBlocking), "hipStreamCreate");
+        HIP_TRY(hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking), "hipStreamCreate");
+    }
+    if (n > P.cap) {
+        for (void** p : {&P.d_in, &P.d_mask, &P.d_out}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        P.cap = 0;
+        HIP_TRY(hipMalloc(&P.d_in, n * 3 * sizeof(float)), "hipMalloc gpu_in.elements");
+        HIP_TRY(hipMalloc(&P.d_mask, n), "hipMalloc gpu_out.elements");
+        HIP_TRY(hipMalloc(&P.d_out, n * 3 * sizeof(float)), "hipMalloc gpu_out.elements");
+        P.cap = n;
+    }
+    const size_t chunk = host_pipeline_chunk();
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    while (P.ev_in.size() < nchunks) {
+        hipEvent_t a = nullptr, b = nullptr, c = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming), "hipEventCreate");
+        HIP_TRY(hipEventCreate(&b), "hipEventCreate");
+        HIP_TRY(hipEventCreate(&c), "hipEventCreate");
+        P.ev_in.push_back(a);
+        P.ev_k0.push_back(b);
+        P.ev_k1.push_back(c);
+    }
+    float* d_in = static_cast<float*>(P.d_in);
+    uint8_t* d_mask = static_cast<uint8_t*>(P.d_mask);
+    float* d_out = static_cast<float*>(P.d_out);
+    // hand-over between the three host threads: how many chunks have their "input landed" / "kernels queued" event recorded
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t in_issued = 0, k_issued = 0;
+    hipError_t err_in = hipSuccess, err_out = hipSuccess;
+    bool abort = false;
+    std::thread t_in([&] {
+        hipError_t e = hipSetDevice(dev);
+        for (size_t c = 0; c < nchunks && e == hipSuccess; c++) {
+            const size_t lo = c * chunk, cnt = std::min(chunk, n - lo);
+            e = hipMemcpyAsync(d_in + 3 * lo, xyz + 3 * lo, cnt * 3 * sizeof(float), hipMemcpyHostToDevice, P.s_in);
+            if (e == hipSuccess) e = hipEventRecord(P.ev_in[c], P.s_in);
+            std::lock_guard<std::mutex> g(mu);
+            if (e != hipSuccess) { err_in = e; abort = true; }
+            else in_issued = c + 1;
+            cv.notify_all();
+            if (abort) break;
+        }
+    });
+    std::thread t_out([&] {
+        hipError_t e = hipSetDevice(dev);
+        for (size_t c = 0; c < nchunks && e == hipSuccess; c++) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return k_issued > c || abort; });
+                if (abort) break;
+            }
+            const size_t lo = c * chunk, cnt = std::min(chunk, n - lo);
+            e = hipStreamWaitEvent(P.s_out, P.ev_k1[c], 0);
+            if (e == hipSuccess && want_mask && mask_out) e = hipMemcpyAsync(mask_out + lo, d_mask + lo, cnt, hipMemcpyDeviceToHost, P.s_out);
+            if (e == hipSuccess && op != 0) e = hipMemcpyAsync(dxyz_out + 3 * lo, d_out + 3 * lo, cnt * 3 * sizeof(float), hipMemcpyDeviceToHost, P.s_out);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(P.s_out);
+        if (e != hipSuccess) {
+            std::lock_guard<std::mutex> g(mu);
+            err_out = e;
+            abort = true;
+            cv.notify_all();
+        }
+    });
+    int rc = LRM_OK;
+    hipError_t err_k = hipSuccess;
+    for (size_t c = 0; c < nchunks; c++) {
+        {
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return in_issued > c || abort; });
+            if (abort) break;
+        }
+        const size_t lo = c * chunk, cnt = std::min(chunk, n - lo);
+        err_k = hipStreamWaitEvent(P.s_k, P.ev_in[c], 0);
+        if (err_k == hipSuccess) err_k = hipEventRecord(P.ev_k0[c], P.s_k);
+        if (err_k == hipSuccess) {
+            if (op == 0) err_k = lrm_launch_reach_aos(d_in + 3 * lo, cnt, L, d_mask + lo, g_mode != LRM_MODE_STRICT, P.s_k);
+            else rc = launch_dist_aos_mode(op, d_in + 3 * lo, cnt, *leg, quat_or_default(quat), L, want_mask ? d_mask + lo : nullptr, d_out + 3 * lo, P.s_k);
+        }
+        if (err_k == hipSuccess && rc == LRM_OK) err_k = hipEventRecord(P.ev_k1[c], P.s_k);
+        std::lock_guard<std::mutex> g(mu);
+        if (err_k != hipSuccess || rc != LRM_OK) abort = true;
+        else k_issued = c + 1;
+        cv.notify_all();
+        if (abort) break;
+    }
+    t_in.join();
+    t_out.join();
+    if (rc != LRM_OK) return rc;
+    HIP_TRY(err_in, "hipMemcpy gpu_in.elements");
+    HIP_TRY(err_k, "Kernel launch");
+    HIP_TRY(err_out, "hipMemcpy gpu_out.elements");
+    float total = 0.f;
+    for (size_t c = 0; c < nchunks; c++) {
+        float e = 0.f;
+        HIP_TRY(hipEventElapsedTime(&e, P.ev_k0[c], P.ev_k1[c]), "hipEventElapsedTime");
+        total += e;
+    }
+    if (ms) *ms = total;
+    return LRM_OK;
+}
+
 // host-buffer skeleton of apply_kernel (cross_compiled.cu:33-79)
 // op: 0 reach, 1 dist, 2 reach+dist
 int host_apply(int op, const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat,
@@ -255,6 +354,8 @@ int host_apply(int op, const float* xyz, size_t n, const LrmLegDimensions* leg, 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LRM_ENODEV, "no HIP device");
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    if (host_pipeline_enabled() && n >= 2 * host_pipeline_chunk())
+        return host_apply_pipelined(op, xyz, n, leg, quat, mask_out, dxyz_out, ms, L);
     DevBuf d_in, d_mask, d_out;
     HIP_TRY(d_in.alloc(n * 3 * sizeof(float)), "hipMalloc gpu_in.elements");
     const bool want_mask = (op != 1) || mask_out;
@@ -805,35 +906,6 @@ int lrm_dbg_tol_host(const float* xyz, size_t n, const LrmLegDimensions* leg, co
     }
     return LRM_OK;
 }
-// as lrm_dbg_tol_host with the plane table in place of the full plane evaluation; doubt bit 0x100 = a candidate's
-// cell carries no answer (the GPU then runs the full evaluation for the point); *n_fine_out = refined cells
-int lrm_dbg_tolgrid_host(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
-                         float* dxyz_out, uint32_t* doubt_out, uint32_t* n_fine_out) {
-    if (!leg || (n && (!xyz || !mask_out || !dxyz_out || !doubt_out))) return fail(LRM_EINVAL, "null argument");
-    LrmCompiledLeg L;
-    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
-    LrmTolLeg TL;
-    lrm_compile_tol(L, &TL);
-    if (!TL.tol_ok) return fail(LRM_EINVAL, "leg not eligible for the tolerance mode");
-    std::vector<uint8_t> grid;
-    const size_t n_fine = lrm_build_tol_grid(TL, LRM_TOLGRID_MAX_FINE, &grid);
-    if (n_fine_out) *n_fine_out = (uint32_t)n_fine;
-    const LrmTolGridHeader* hd = reinterpret_cast<const LrmTolGridHeader*>(grid.data());
-    const uint16_t* coarse = reinterpret_cast<const uint16_t*>(grid.data() + sizeof(LrmTolGridHeader));
-    const uint8_t* fine = grid.data() + sizeof(LrmTolGridHeader) + (size_t)LRM_TG_N * LRM_TG_N * 2;
-    const LrmTolTables T{&TL.circ[0][0], &TL.feat[0]};
-    const LrmTolGridView G{coarse, fine, hd->band_max};
-    for (size_t i = 0; i < n; i++) {
-        LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-        uint32_t doubt = 0;
-        mask_out[i] = lrm_dist_tolgrid(TL, T, G, p, doubt);
-        dxyz_out[3 * i] = p.x;
-        dxyz_out[3 * i + 1] = p.y;
-        dxyz_out[3 * i + 2] = p.z;
-        doubt_out[i] = doubt;
-    }
-    return LRM_OK;
-}
 // as lrm_dbg_tol_host with the plane table with deferred decisions (lrm_toltab.cpp) in place of the full plane evaluation;
 // doubt bit 0x100 = a cell without an answer.  stats_out[4] (optional): rows, validity rows, refined cells, table bytes
 int lrm_dbg_toltab_host(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
@@ -847,18 +919,17 @@ int lrm_dbg_toltab_host(const float* xyz, size_t n, const LrmLegDimensions* leg,
     std::vector<uint8_t> tab;
     if (!lrm_build_tol_tab(TL, &tab)) return fail(LRM_EINVAL, "leg needs more table rows than a cell code can name");
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab.data());
-    const uint16_t* coarse = reinterpret_cast<const uint16_t*>(tab.data() + sizeof(LrmTolTabHeader));
-    const LrmTolTabView G{hd->rows, hd->vrows, coarse, coarse + (size_t)LRM_TT_N * LRM_TT_N, hd->band_max};
+    const LrmTolTabView G = lrm_toltab_view(tab.data(), hd->rows, hd->vrows);
     if (stats_out) {
         stats_out[0] = hd->n_rows;
         stats_out[1] = hd->n_vrows;
-        stats_out[2] = hd->n_fine;
+        stats_out[2] = hd->n_fine[0] + hd->n_fine[1];
         stats_out[3] = (uint32_t)tab.size();
     }
     for (size_t i = 0; i < n; i++) {
         LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         uint32_t doubt = 0;
-        mask_out[i] = lrm_dist_toltab(TL, G, p, doubt);
+        mask_out[i] = lrm_tab_point(TL, G, p, doubt);
         dxyz_out[3 * i] = p.x;
         dxyz_out[3 * i + 1] = p.y;
         dxyz_out[3 * i + 2] = p.z;
@@ -866,19 +937,39 @@ int lrm_dbg_toltab_host(const float* xyz, size_t n, const LrmLegDimensions* leg,
     }
     return LRM_OK;
 }
-// After a plane-table call in LRM_MODE_TOL (synchronises the device): how many points went to the full evaluation
-// (queue A) and how many of those on to the bit-exact code (queue B).
-int lrm_dbg_tol_queue_counts(uint64_t* n_points, uint64_t* n_full, uint64_t* n_exact) {
-    if (!g_tol_last.ws || !n_points || !n_full || !n_exact) return fail(LRM_EINVAL, "no plane-table call yet");
-    HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
-    std::vector<uint32_t> c(2 * g_tol_last.waves);
-    const uint32_t* counts = g_tol_last.ws + 2 * g_tol_last.waves * g_tol_last.seg_cap;
-    HIP_TRY(hipMemcpy(c.data(), counts, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy counts");
-    uint64_t a = 0, b = 0;
-    for (size_t i = 0; i < g_tol_last.waves; i++) { a += c[i]; b += c[g_tol_last.waves + i]; }
+// Counting build only (-DLRM_PAIR_COUNT, tools/c3_evidence.py): what reach_any_wave_kernel evaluated since the last call:
+// out[0] full (leg, target) evaluations, [1] leg bounding-sphere tests, [2] footholds inside a body's reach sphere, [3] footholds loaded
+int lrm_dbg_pair_counts(uint64_t out[4]) {
+    if (!out) return fail(LRM_EINVAL, "null argument");
+    unsigned long long c[4] = {0, 0, 0, 0};
+    const hipError_t e = lrm_pair_counts(c);
+    if (e == hipErrorNotSupported) return fail(LRM_EINVAL, "this library was built without -DLRM_PAIR_COUNT");
+    HIP_TRY(e, "pair counters");
+    for (int i = 0; i < 4; i++) out[i] = c[i];
+    return LRM_OK;
+}
+// After a distance / fused call on device buffers in LRM_MODE_TOL (synchronises that device): how many of its points the
+// main kernel queued for the bit-exact fix-up, and how many workgroups overflowed their queue segment (their points are
+// all re-evaluated).  Valid until the next tolerance-mode call on a larger cloud regrows the workspace.
+int lrm_dbg_tol_queue_counts(uint64_t* n_points, uint64_t* n_queued, uint64_t* n_overflowed) {
+    if (!n_points || !n_queued || !n_overflowed) return fail(LRM_EINVAL, "null argument");
+    if (!g_tol_last.counts) return fail(LRM_EINVAL, "no tolerance-mode call on device buffers yet");
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur), "hipGetDevice");
+    HIP_TRY(hipSetDevice(g_tol_last.dev), "hipSetDevice");
+    std::vector<uint32_t> c(g_tol_last.blocks);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(c.data(), g_tol_last.counts, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipSetDevice(cur);
+    HIP_TRY(e, "hipMemcpy counts");
+    uint64_t q = 0, o = 0;
+    for (uint32_t v : c) {
+        q += v;
+        o += v > (uint32_t)LRM_TOL_SEG_CAP_WORDS;
+    }
     *n_points = g_tol_last.n;
-    *n_full = a;
-    *n_exact = b;
+    *n_queued = q;
+    *n_overflowed = o;
     return LRM_OK;
 }
 int lrm_dbg_tol_ok(const LrmLegDimensions* leg, const float* quat) {
@@ -889,6 +980,54 @@ int lrm_dbg_tol_ok(const LrmLegDimensions* leg, const float* quat) {
     lrm_compile_tol(L, &TL);
     return TL.tol_ok;
 }
+
+namespace {
+// The orientation loop of robot_full_struct (several_leg.cu:831-857 -> runPipeline :762-787) on device-resident clouds:
+// per orientation rotate both clouds, (optionally) the cylinder culls of eliminateFarAndColliding (:504-525), every
+// leg's any-target reachability, and the monotone acceptance (an `active` byte per body).  Everything on the null
+// stream; only launches (the per-orientation leg data is a few hundred bytes of kernel arguments).
+// b*/t*: the unrotated clouds (SoA), rb*/rt*: scratch for the rotated ones, rot_dev: nquat LrmCompiledLeg slots,
+// m1/m2: max(nb, nt) bytes, leg_body: nlegs * nb, all: nb, active (in/out) and accepted (in/out): nb bytes.
+int sweep_orientations_dev(const float* bx, const float* by, const float* bz, size_t nb, const float* tx, const float* ty, const float* tz, size_t mt,
+                           const LrmLegDimensions* legs, size_t nlegs, const float* quats, size_t nquat, int culls,
+                           float* rbx, float* rby, float* rbz, float* rtx, float* rty, float* rtz, LrmCompiledLeg* rot_dev,
+                           uint8_t* m1, uint8_t* m2, uint8_t* leg_body, uint8_t* all, uint8_t* active, uint8_t* accepted) {
+    {   // every orientation's qtRotate coefficients in one upload: the loop below only launches
+        std::vector<LrmCompiledLeg> rots(nquat);
+        LrmLegDimensions dummy{};
+        for (size_t qi = 0; qi < nquat; qi++) lrm_compile_leg(dummy, quats + 4 * qi, 0, &rots[qi]); // only fwd_rot is used
+        if (nquat) HIP_TRY(hipMemcpy(rot_dev, rots.data(), sizeof(LrmCompiledLeg) * nquat, hipMemcpyHostToDevice), "hipMemcpy rotations");
+    }
+    for (size_t qi = 0; qi < nquat; qi++) {
+        const float* q = quats + 4 * qi;
+        LrmLegDimensions rl[LRM_MAX_LEGS];
+        for (size_t l = 0; l < nlegs; l++) lrm_host_rotate_leg_data(q, legs[l], &rl[l]);
+        HIP_TRY(lrm_launch_rotate_soa(bx, by, bz, nb, rot_dev + qi, rbx, rby, rbz, nullptr), "rotate bodies");
+        if (mt) HIP_TRY(lrm_launch_rotate_soa(tx, ty, tz, mt, rot_dev + qi, rtx, rty, rtz, nullptr), "rotate targets");
+        bool boxes_ready = false; // the kernels of one orientation share the rotated cloud's boxes: only the first builds them
+        int rc = LRM_OK;
+        if (culls) {
+            // eliminateFarAndColliding, several_leg.cu:504-525, with the rotated leg 0
+            const LrmLegDimensions& d = rl[0];
+            const float s_pitch = sinf(d.coxa_pitch), c_pitch = cosf(d.coxa_pitch);
+            const float radius_in = d.body + c_pitch * d.coxa_length + d.femur_length + d.tibia_length;
+            const float half_pi = 3.14159265358979323846264338327950288419716939937510582097f / 2;
+            const float plus_abs = d.tibia_length * sinf(d.tibia_absolute_pos) +
+                                   d.femur_length * sinf(half_pi < d.max_angle_femur ? half_pi : d.max_angle_femur);
+            const float plus_z_in = s_pitch * d.coxa_length + plus_abs;
+            const float minus_z_in = s_pitch * d.coxa_length - d.femur_length - d.tibia_length;
+            rc = any_in_shape_impl(1, rbx, rby, rbz, nb, rtx, rty, rtz, mt, radius_in, plus_z_in, minus_z_in, boxes_ready, m1, nullptr);
+            boxes_ready = mt >= 4096;
+            if (rc == LRM_OK) rc = any_in_shape_impl(1, rbx, rby, rbz, nb, rtx, rty, rtz, mt, d.body, 250.f, -110.f, boxes_ready, m2, nullptr);
+            if (rc != LRM_OK) return rc;
+        }
+        rc = reach_any_impl(rbx, rby, rbz, nb, rtx, rty, rtz, mt, rl, nlegs, q, active, boxes_ready, leg_body, all, nullptr);
+        if (rc != LRM_OK) return rc;
+        HIP_TRY(lrm_launch_sweep_update(all, m1, m2, culls ? 1 : 0, nb, active, accepted, nullptr), "sweep update");
+    }
+    return LRM_OK;
+}
+} // namespace
 
 // robot_full_struct's pipeline (several_leg.cu:326-877) with masks instead of thrust stream
 // compaction, resident on the device from the first upload to the final mask.
@@ -994,46 +1133,12 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
     }
     HIP_TRY(hipMemcpy(d_active.p, active.data(), nb, hipMemcpyHostToDevice), "hipMemcpy active");
 
-    {   // every orientation's qtRotate coefficients in one upload: the loop below only launches
-        std::vector<LrmCompiledLeg> rots(nquat);
-        LrmLegDimensions dummy{};
-        for (size_t qi = 0; qi < nquat; qi++) lrm_compile_leg(dummy, quats + 4 * qi, 0, &rots[qi]); // only fwd_rot is used
-        if (nquat) HIP_TRY(hipMemcpy(d_rot.p, rots.data(), sizeof(LrmCompiledLeg) * nquat, hipMemcpyHostToDevice), "hipMemcpy rotations");
-    }
-    bool boxes_ready = false; // the kernels of one orientation share the rotated cloud's boxes: only the first builds them
     HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
-    for (size_t qi = 0; qi < nquat; qi++) {
-        const float* q = quats + 4 * qi;
-        LrmLegDimensions rl[LRM_MAX_LEGS];
-        for (size_t l = 0; l < nlegs; l++) lrm_host_rotate_leg_data(q, legs[l], &rl[l]);
-        const LrmCompiledLeg* rot_dev = d_rot.as<LrmCompiledLeg>() + qi;
-        HIP_TRY(lrm_launch_rotate_soa(B0, B0 + pb, B0 + 2 * pb, nb, rot_dev, B, B + pb, B + 2 * pb, nullptr), "rotate bodies");
-        if (mt) HIP_TRY(lrm_launch_rotate_soa(T0, T0 + pt, T0 + 2 * pt, mt, rot_dev, T, T + pt, T + 2 * pt, nullptr), "rotate targets");
-        boxes_ready = false; // new rotated cloud
-        int rc = LRM_OK;
-        if (reference_culls) {
-            // eliminateFarAndColliding, several_leg.cu:504-525, with the rotated leg 0
-            const LrmLegDimensions& d = rl[0];
-            const float s_pitch = sinf(d.coxa_pitch), c_pitch = cosf(d.coxa_pitch);
-            const float radius_in = d.body + c_pitch * d.coxa_length + d.femur_length + d.tibia_length;
-            const float half_pi = 3.14159265358979323846264338327950288419716939937510582097f / 2;
-            const float plus_abs = d.tibia_length * sinf(d.tibia_absolute_pos) +
-                                   d.femur_length * sinf(half_pi < d.max_angle_femur ? half_pi : d.max_angle_femur);
-            const float plus_z_in = s_pitch * d.coxa_length + plus_abs;
-            const float minus_z_in = s_pitch * d.coxa_length - d.femur_length - d.tibia_length;
-            rc = any_in_shape_impl(1, B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, radius_in, plus_z_in, minus_z_in,
-                                   boxes_ready, d_m1.as<uint8_t>(), nullptr);
-            boxes_ready = mt >= 4096;
-            if (rc == LRM_OK)
-                rc = any_in_shape_impl(1, B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, d.body, 250.f, -110.f,
-                                       boxes_ready, d_m2.as<uint8_t>(), nullptr);
-            if (rc != LRM_OK) return rc;
-        }
-        rc = reach_any_impl(B, B + pb, B + 2 * pb, nb, T, T + pt, T + 2 * pt, mt, rl, nlegs, q, d_active.as<uint8_t>(),
-                            boxes_ready, d_leg_body.as<uint8_t>(), d_all.as<uint8_t>(), nullptr);
+    {
+        const int rc = sweep_orientations_dev(B0, B0 + pb, B0 + 2 * pb, nb, T0, T0 + pt, T0 + 2 * pt, mt, legs, nlegs, quats, nquat, reference_culls ? 1 : 0,
+                                              B, B + pb, B + 2 * pb, T, T + pt, T + 2 * pt, d_rot.as<LrmCompiledLeg>(), d_m1.as<uint8_t>(), d_m2.as<uint8_t>(),
+                                              d_leg_body.as<uint8_t>(), d_all.as<uint8_t>(), d_active.as<uint8_t>(), d_accepted.as<uint8_t>());
         if (rc != LRM_OK) return rc;
-        HIP_TRY(lrm_launch_sweep_update(d_all.as<uint8_t>(), d_m1.as<uint8_t>(), d_m2.as<uint8_t>(), reference_culls ? 1 : 0, nb,
-                                        d_active.as<uint8_t>(), d_accepted.as<uint8_t>(), nullptr), "sweep update");
     }
     HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
     HIP_TRY(hipMemcpy(h2.data(), d_accepted.p, nb, hipMemcpyDeviceToHost), "hipMemcpy result");
@@ -1042,6 +1147,52 @@ int lrm_positionability(const float* bodies, size_t nb, const float* targets, si
     HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
     total_ms += e;
     if (ms) *ms = total_ms;
+    return LRM_OK;
+}
+
+// lrm_positionability on clouds that already live on the device (SoA float32) with device-resident masks in and out: the
+// orientation sweep alone (reference_culls 0: none; 2: the per-orientation cylinder culls -- the caller has applied the
+// one-time culls of multi_rot_estimator, several_leg.cu:413-502, as the sharded drivers do).  active_in: NULL = every
+// body.  No copies of the clouds, no reordering (feed Morton-ordered clouds: lrm_morton_order); returns after the device
+// has finished (null stream).
+int lrm_positionability_dev(const float* bx, const float* by, const float* bz, size_t nb, const float* tx, const float* ty,
+                            const float* tz, size_t nt, const LrmLegDimensions* legs, size_t nlegs, const float* quats,
+                            size_t nquat, int reference_culls, const uint8_t* active_in, uint8_t* accepted_out, float* ms) {
+    if (!legs || nlegs == 0 || nlegs > LRM_MAX_LEGS) return fail(LRM_EINVAL, "nlegs must be 1..LRM_MAX_LEGS");
+    if ((nb && (!bx || !by || !bz || !accepted_out)) || (nt && (!tx || !ty || !tz)) || (nquat && !quats)) return fail(LRM_EINVAL, "null argument");
+    if (reference_culls != 0 && reference_culls != 2) return fail(LRM_EINVAL, "reference_culls must be 0 or 2 here (the one-time culls are the caller's)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LRM_ENODEV, "no HIP device");
+    if (ms) *ms = 0.f;
+    if (nb == 0) return LRM_OK;
+    Events ev;
+    HIP_TRY(hipEventCreate(&ev.a), "hipEventCreate");
+    HIP_TRY(hipEventCreate(&ev.b), "hipEventCreate");
+    const size_t pb = (nb + 3) & ~(size_t)3, pt = ((nt ? nt : 1) + 3) & ~(size_t)3;
+    DevBuf d_b, d_t, d_m1, d_m2, d_leg_body, d_all, d_active, d_rot;
+    HIP_TRY(d_b.alloc(3 * pb * sizeof(float)), "hipMalloc bodies");
+    HIP_TRY(d_t.alloc(3 * pt * sizeof(float)), "hipMalloc targets");
+    HIP_TRY(d_m1.alloc(nb > nt ? nb : nt), "hipMalloc mask");
+    HIP_TRY(d_m2.alloc(nb > nt ? nb : nt), "hipMalloc mask");
+    HIP_TRY(d_leg_body.alloc(nlegs * nb), "hipMalloc leg results");
+    HIP_TRY(d_all.alloc(nb), "hipMalloc body results");
+    HIP_TRY(d_active.alloc(nb), "hipMalloc active");
+    HIP_TRY(d_rot.alloc(sizeof(LrmCompiledLeg) * (nquat ? nquat : 1)), "hipMalloc rotations");
+    if (active_in) HIP_TRY(hipMemcpy(d_active.p, active_in, nb, hipMemcpyDeviceToDevice), "hipMemcpy active");
+    else HIP_TRY(hipMemset(d_active.p, 1, nb), "hipMemset active");
+    HIP_TRY(hipMemset(accepted_out, 0, nb), "hipMemset accepted");
+    float* B = d_b.as<float>();
+    float* T = d_t.as<float>();
+    HIP_TRY(hipEventRecord(ev.a, nullptr), "hipEventRecord");
+    const int rc = sweep_orientations_dev(bx, by, bz, nb, tx, ty, tz, nt, legs, nlegs, quats, nquat, reference_culls ? 1 : 0, B, B + pb, B + 2 * pb,
+                                          T, T + pt, T + 2 * pt, d_rot.as<LrmCompiledLeg>(), d_m1.as<uint8_t>(), d_m2.as<uint8_t>(),
+                                          d_leg_body.as<uint8_t>(), d_all.as<uint8_t>(), d_active.as<uint8_t>(), accepted_out);
+    if (rc != LRM_OK) return rc;
+    HIP_TRY(hipEventRecord(ev.b, nullptr), "hipEventRecord");
+    HIP_TRY(hipEventSynchronize(ev.b), "hipEventSynchronize");
+    float e = 0.f;
+    HIP_TRY(hipEventElapsedTime(&e, ev.a, ev.b), "hipEventElapsedTime");
+    if (ms) *ms = e;
     return LRM_OK;
 }
 

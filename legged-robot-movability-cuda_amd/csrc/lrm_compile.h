@@ -25,10 +25,6 @@ void lrm_host_leg_factory(float azimut, float body2coxa, float coxa_pitch_deg, f
 // the leg is not eligible for the filters at all): callers then use LRM_MODE_FAST for that leg.
 void lrm_compile_tol(const LrmCompiledLeg& L, LrmTolLeg* out);
 
-// The plane table of the tolerance mode (lrm_types.h: LrmTolGridHeader | uint16 coarse[LRM_TG_N^2] | uint8 fine[16 n_fine])
-// for an eligible leg; at most max_fine coarse cells are refined.  Returns n_fine.
-size_t lrm_build_tol_grid(const LrmTolLeg& L, size_t max_fine, std::vector<uint8_t>* out);
-
 // The plane table with deferred decisions (lrm_types.h: LrmTolTabHeader | uint16 coarse[LRM_TT_N^2] | uint16 fine[16 (n_fine + 1)]).
 // false: the leg needs more distinct rows than a cell code can name -- the caller uses the kernels without a table.
 bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out);

@@ -582,6 +582,17 @@ __global__ __launch_bounds__(kBlock, LRM_ANY_MIN_WAVES) void reach_any_kernel(
 // current one is tested.  No tile staging in LDS, no block barriers (reach_any_kernel waits on
 // them half of the time: four bodies advance in lockstep through every tile any of them needs),
 // and a finished body leaves at once.
+// -DLRM_PAIR_COUNT: a counting build (tools/c3_evidence.py; never the shipped library): how many (leg, target) pairs
+// the wave-per-body kernel really evaluates, against the nb * nt * nlegs pairs it answers.
+//   [0] full evaluations (lrm_reachable_rotate_leg*), [1] leg bounding-sphere tests, [2] footholds inside a body's
+//   reach sphere (queued), [3] footholds loaded
+#if defined(LRM_PAIR_COUNT)
+__device__ unsigned long long g_pair_count[4];
+#define LRM_COUNT_PAIRS(k, ballot_mask) do { const unsigned long long bm_ = (ballot_mask); /* the ballot with every lane active */ \
+        if (lane == 0) atomicAdd(&g_pair_count[k], (unsigned long long)__builtin_popcountll(bm_)); } while (0)
+#else
+#define LRM_COUNT_PAIRS(k, ballot_mask) do {} while (0)
+#endif
 #ifndef LRM_ANY_WAVE_MIN_WAVES
 #define LRM_ANY_WAVE_MIN_WAVES 8 // latency-bound on its L2 loads: 4 / 5 / 6 / 8 waves per SIMD -> 1.10 / 1.10 / 1.03 / 0.98 ms
 #endif
@@ -625,6 +636,8 @@ __global__ __launch_bounds__(kBlock, LRM_ANY_WAVE_MIN_WAVES) void reach_any_wave
                 // mostly lies outside the spheres of all but two or three legs
                 const float ex = rx - legs[l].pair_center[0], ey = ry - legs[l].pair_center[1], ez = rz - legs[l].pair_center[2];
                 const bool inside = (lane < m) && __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) <= legs[l].pair_r2;
+                LRM_COUNT_PAIRS(1, __ballot(lane < m));
+                LRM_COUNT_PAIRS(0, __ballot(inside));
                 if (__ballot(inside) == 0ull) continue;
                 bool hit = false;
                 if (inside) {
@@ -685,6 +698,8 @@ __global__ __launch_bounds__(kBlock, LRM_ANY_WAVE_MIN_WAVES) void reach_any_wave
                     const float ddx = t.x - body.x, ddy = t.y - body.y, ddz = t.z - body.z;
                     const bool keep = ok && __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx)) <= r2max;
                     const unsigned long long m = __ballot(keep);
+                    LRM_COUNT_PAIRS(3, __ballot(ok));
+                    LRM_COUNT_PAIRS(2, m);
                     if (m == 0ull) continue;
                     if (keep) {
                         const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1098,4 +1113,19 @@ hipError_t lrm_launch_sweep_update(const uint8_t* all_legs, const uint8_t* cyl_v
     hipLaunchKernelGGL(sweep_update_kernel, dim3(grid_for(nb)), dim3(kBlock), 0, st, all_legs, cyl_validate, cyl_eliminate,
                        use_culls, nb, active, accepted);
     return hipGetLastError();
+}
+
+// counters of a -DLRM_PAIR_COUNT build (read and reset); an ordinary build has none
+hipError_t lrm_pair_counts(unsigned long long out[4]) {
+#if defined(LRM_PAIR_COUNT)
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_count), 4 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    const unsigned long long zero[4] = {0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pair_count), zero, sizeof zero);
+#else
+    (void)out;
+    return hipErrorNotSupported;
+#endif
 }

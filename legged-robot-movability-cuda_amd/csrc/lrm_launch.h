@@ -13,6 +13,10 @@ hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const flo
 // LRM_MODE_TOL (lrm_tol_kernels.hip): the tolerance kernel + the fix-up of its doubtful points, two launches on
 // `st`.  workspace: lrm_tol_queue_words(n) uint32 of device memory owned by the caller for the duration of both
 // launches (contents are rewritten by every call; no initialisation needed).
+#ifndef LRM_TOL_SEG_CAP
+#define LRM_TOL_SEG_CAP 128 // doubt slots per workgroup of the main kernel (768 points): 17 %.  32 overflowed on the reference's planar bench grid (7 % in doubt: it contains the coxa axis and the symmetry plane)
+#endif
+#define LRM_TOL_SEG_CAP_WORDS LRM_TOL_SEG_CAP
 size_t lrm_tol_queue_words(size_t n);
 hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, uint8_t* mask,
                                    float* dxyz, uint32_t* workspace, hipStream_t st);
@@ -26,13 +30,6 @@ hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const flo
                                float* dz, uint32_t* workspace, hipStream_t st);
 hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const uint8_t* tab_dev,
                                    uint8_t* mask, float* dxyz, uint32_t* workspace, hipStream_t st);
-// Plane-table variant of LRM_MODE_TOL (three launches on `st`).  grid_dev: device copy of the table built by
-// lrm_build_tol_grid (grid_bytes bytes).  lrm_tolgrid_plan gives the launch geometry and the uint32 words of
-// device workspace the call needs (rewritten by every call).
-void lrm_tolgrid_plan(size_t n, size_t grid_bytes, uint32_t* blocks_out, uint32_t* seg_cap_out, size_t* workspace_words_out);
-hipError_t lrm_launch_dist_tolgrid(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
-                                   const LrmTolLeg& TL, const uint8_t* grid_dev, size_t grid_bytes, uint8_t* mask,
-                                   uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace, hipStream_t st);
 hipError_t lrm_launch_reach_aos(const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask, bool fast,
                                 hipStream_t st);
 hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask,
@@ -55,3 +52,5 @@ hipError_t lrm_launch_rotate_soa(const float* sx, const float* sy, const float* 
                                  float* dx, float* dy, float* dz, hipStream_t st);
 hipError_t lrm_launch_sweep_update(const uint8_t* all_legs, const uint8_t* cyl_validate, const uint8_t* cyl_eliminate,
                                    int use_culls, size_t nb, uint8_t* active, uint8_t* accepted, hipStream_t st);
+// evaluation counters of reach_any_wave_kernel in a -DLRM_PAIR_COUNT build (read and reset); hipErrorNotSupported otherwise
+hipError_t lrm_pair_counts(unsigned long long out[4]);

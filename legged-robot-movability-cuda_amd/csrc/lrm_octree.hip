@@ -382,6 +382,10 @@ bool create_child_box(const Node& parent, unsigned index, float min_box, Node* c
 }
 
 thread_local std::string g_oct_err;
+// lrm_dbg_oct_trace: every evaluated child of every level of the calls that follow, with the flag bits its kernel
+// returned (tests compare a sample of them with the oracle): {c[3], h[3], parent h[3], flags, parent_valid + 2 rot + 4 skip, depth}
+thread_local bool g_oct_trace = false;
+thread_local std::vector<float> g_oct_trace_recs;
 
 } // namespace
 
@@ -407,6 +411,18 @@ void lrm_octree_default_settings(LrmOctreeSettings* s) {
 }
 
 const char* lrm_octree_last_error(void) { return g_oct_err.c_str(); }
+
+int lrm_dbg_oct_trace(int enable) {
+    g_oct_trace = enable != 0;
+    g_oct_trace_recs.clear();
+    return 0;
+}
+int lrm_dbg_oct_trace_read(float* out, size_t capacity_records, size_t* n_out) {
+    if (!n_out) return -1;
+    *n_out = g_oct_trace_recs.size() / 12;
+    if (out && capacity_records >= *n_out) std::memcpy(out, g_oct_trace_recs.data(), g_oct_trace_recs.size() * sizeof(float));
+    return 0;
+}
 
 // apply_oct, several_leg_octree.cu:391-488
 static int apply_oct_impl(const float* footholds, const float* dev_x, const float* dev_y, const float* dev_z, size_t nf,
@@ -684,6 +700,13 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
         }
         if (dbg) { fprintf(stderr, "apply_oct: level %d, %zu children: %.2f ms (host + kernel)\n", depth, nc, ms_since(t_phase)); t_phase = now(); }
         if (world > 1) exchange(flags.data(), nc, user);
+        if (g_oct_trace)
+            for (size_t k = 0; k < nc; k++) {
+                const OctChild& oc = level[k];
+                const float rec[12] = {oc.c[0], oc.c[1], oc.c[2], oc.h[0], oc.h[1], oc.h[2], oc.ph[0], oc.ph[1], oc.ph[2], (float)(flags[k] & 7u),
+                                       (float)((oc.parent_valid ? 1 : 0) + (oc.n_angles > 1 ? 2 : 0) + (oc.skip ? 4 : 0)), (float)depth};
+                g_oct_trace_recs.insert(g_oct_trace_recs.end(), rec, rec + 12);
+            }
         // several_leg_octree.cu:134-150, with global ORs
         std::vector<int> next;
         for (size_t k = 0; k < nc; k++) {

@@ -58,8 +58,10 @@
 // all lanes of the wave agree (device) / this point (host)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LRM_TOL_ALL(c) (__all(c))
+#define LRM_TOL_ANY(c) (__any(c))
 #else
 #define LRM_TOL_ALL(c) (c)
+#define LRM_TOL_ANY(c) (c)
 #endif
 #ifndef LRM_TOL_TIE
 #define LRM_TOL_TIE 0.25f
@@ -85,7 +87,7 @@
 #define LRM_TD_NONE 16u    // no clamp target at all (the reference then returns the raw point), or an ill-conditioned clamp
 #define LRM_TD_LIMIT 32u   // yaw-limit alternative ties with the in-plane distance, or the two limits tie
 #define LRM_TD_PICK 64u    // the two yaw candidates tie
-#define LRM_TD_AMBIG 0x100u // plane-table variant: the cell of a candidate's plane point carries no answer (or the band exceeds the table's)
+#define LRM_TD_AMBIG 0x100u // table kernel: the cell of a candidate's plane point carries no answer
 #endif
 #define LRM_TD_SECOND 0x10000u // statistic only: the second candidate could not be pruned by its lower bound
 
@@ -232,7 +234,7 @@ LRM_HD void lrm_tol_plane(const LrmTolLeg& L, const LrmTolTables T, float u, flo
 #endif
 }
 
-// ---- plane evaluators: the full evaluation above, or the plane table (lrm_types.h, lrm_tolgrid.cpp) ----
+// ---- plane evaluator of lrm_dist_tol_t: the full evaluation above ----
 struct LrmTolPlaneFull {
     static constexpr bool kSkipSame = true; // a wave whose lanes all have one configuration skips the second evaluation
     const LrmTolLeg& L;
@@ -242,73 +244,60 @@ struct LrmTolPlaneFull {
     }
 };
 
-struct LrmTolGridView {
-    const uint16_t* coarse; // [LRM_TG_N * LRM_TG_N]
-    const uint8_t* fine;    // [16 * max(n_fine, 1)]
-    float band_max;
-};
-// code of the cell of plane point (x = abscissa - coxa_length, z), or LRM_TG_AMBIG8.  Branch-free: every lane
-// reads one coarse entry and one fine byte.
-LRM_HD uint32_t lrm_tolgrid_lookup(const LrmTolGridView G, float x, float z) {
-    const float fx = (x + LRM_TG_HALF) * (1.0f / LRM_TG_H), fz = (z + LRM_TG_HALF) * (1.0f / LRM_TG_H);
-    // inside [0, N): also false for nan
-    const bool inside = (fx >= 0.f) && (fx < (float)LRM_TG_N) && (fz >= 0.f) && (fz < (float)LRM_TG_N);
-    const int ix = inside ? (int)fx : 0, iz = inside ? (int)fz : 0;
-    const uint32_t c = G.coarse[iz * LRM_TG_N + ix];
-    const int sx = (int)((fx - (float)ix) * 4.0f) & 3, sz = (int)((fz - (float)iz) * 4.0f) & 3;
-    const bool refined = (c & 0x8000u) && c != LRM_TG_AMBIG16;
-    const uint32_t f = G.fine[refined ? ((c & 0x7fffu) * 16u + (uint32_t)(sz * 4 + sx)) : 0u];
-    const uint32_t code = refined ? f : (c < 64u ? c : (uint32_t)LRM_TG_AMBIG8);
-    return inside ? code : (uint32_t)LRM_TG_AMBIG8;
-}
-struct LrmTolPlaneGrid {
-    static constexpr bool kSkipSame = false; // two short lookups: straight-line code lets their LDS reads overlap
-    const LrmTolLeg& L;
-    LrmTolTables T;
-    LrmTolGridView G;
-    LRM_HD void operator()(float u, float z, float band, float tau, float& du, float& dz, bool& valid, uint32_t& doubt) const {
-        const float x = u - L.coxa_length;
-        const uint32_t code = lrm_tolgrid_lookup(G, x, z);
-        const LrmCircle f = T.feat[code & 31u];
-        const float vx = x - f.x, vy = z - f.y;
-        const float m = __builtin_fmaf(vy, vy, vx * vx);
-        const float s = __builtin_fmaf(-f.r, LRM_FAST_RSQ(m), 1.0f);
-        du = vx * s;
-        dz = vy * s;
-        valid = (code & 32u) != 0u;
-        doubt |= (code == (uint32_t)LRM_TG_AMBIG8 || !(band <= G.band_max)) ? LRM_TD_AMBIG : 0u;
-        (void)tau;
-    }
-};
-
 // ---- plane table with deferred decisions (lrm_types.h LrmTolTabHeader, lrm_toltab.cpp) ----
 struct LrmTolTabView {
     const LrmTabRow* rows;   // [32]
     const LrmTabVRow* vrows; // [32]
-    const uint16_t* coarse;  // [LRM_TT_N * LRM_TT_N]
-    const uint16_t* fine;    // [LRM_TT_SUB^2 * (n_fine + 1)]
-    float band_max;
+    const uint16_t* cells;   // the grids' coarse and fine arrays (behind the header)
+    float band_max, far_limit;
+    float inv_h[2];
+    uint32_t coarse_off[2], fine_off[2];
 };
-// code of the cell of plane point (x = abscissa - coxa_length, z), or LRM_TT_UNANSWERED.  Branch-free: every lane
-// reads one coarse entry and one fine entry.
-LRM_HD uint32_t lrm_toltab_lookup(const LrmTolTabView G, float x, float z) {
-    const float fx = __builtin_fmaf(x, 1.0f / LRM_TT_H, LRM_TT_HALF / LRM_TT_H), fz = __builtin_fmaf(z, 1.0f / LRM_TT_H, LRM_TT_HALF / LRM_TT_H);
-    // inside [0, N): also false for nan
-    const bool inside = (fx >= 0.f) && (fx < (float)LRM_TT_N) && (fz >= 0.f) && (fz < (float)LRM_TT_N);
-    const int ix = inside ? (int)fx : 0, iz = inside ? (int)fz : 0;
-    const uint32_t c = G.coarse[iz * LRM_TT_N + ix];
-    const int sx = (int)((fx - (float)ix) * (float)LRM_TT_SUB) & (LRM_TT_SUB - 1), sz = (int)((fz - (float)iz) * (float)LRM_TT_SUB) & (LRM_TT_SUB - 1);
-    const bool refined = (c & 0x8000u) != 0u;
-    const uint32_t f = G.fine[refined ? ((c & 0x7fffu) * (uint32_t)(LRM_TT_SUB * LRM_TT_SUB) + (uint32_t)(sz * LRM_TT_SUB + sx)) : 0u];
-    const uint32_t code = refined ? f : c;
-    return inside ? code : (uint32_t)LRM_TT_UNANSWERED;
+// rows / vrows: where the caller keeps the rows (the kernel: its LDS copy; the host: the header's own)
+LRM_HD LrmTolTabView lrm_toltab_view(const uint8_t* tab, const LrmTabRow* rows, const LrmTabVRow* vrows) {
+    const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
+    return LrmTolTabView{rows, vrows, reinterpret_cast<const uint16_t*>(tab + sizeof(LrmTolTabHeader)),
+                         hd->band_max, hd->far_limit, {hd->inv_h[0], hd->inv_h[1]}, {hd->coarse_off[0], hd->coarse_off[1]},
+                         {hd->fine_off[0], hd->fine_off[1]}};
+}
+// cells[i] of the table (global memory).  Device: "uniform base + 32-bit offset" addressing (global_load_ushort with an
+// SGPR base) instead of a 64-bit address per lane.
+#if defined(__HIP_DEVICE_COMPILE__)
+LRM_HD uint32_t lrm_tt_cell(const uint16_t* cells, uint32_t i) {
+    typedef const __attribute__((address_space(1))) char* GP;
+    return *(const __attribute__((address_space(1))) uint16_t*)((GP)cells + (i << 1));
+}
+#else
+LRM_HD uint32_t lrm_tt_cell(const uint16_t* cells, uint32_t i) { return cells[i]; }
+#endif
+// Look-up of two plane points (x0, z), (x1, z) of one point on the grid (inv, cbase, fbase): the codes of their cells, or
+// LRM_TT_UNANSWERED.  Straight-line code: every lane reads one coarse and one fine entry per plane point, the two coarse
+// loads are issued together, then the two fine loads.
+LRM_HD void lrm_toltab_lookup2(const uint16_t* cells, float inv, uint32_t cbase, uint32_t fbase, float x0, float x1, float z,
+                               uint32_t& code0, uint32_t& code1) {
+    const float fz = __builtin_fmaf(z, inv, LRM_TT_OFF), fx0 = __builtin_fmaf(x0, inv, LRM_TT_OFF), fx1 = __builtin_fmaf(x1, inv, LRM_TT_OFF);
+    const float gz = __builtin_floorf(fz), gx0 = __builtin_floorf(fx0), gx1 = __builtin_floorf(fx1);
+    const int iz = (int)gz, ix0 = (int)gx0, ix1 = (int)gx1; // saturating conversions, nan -> 0 (a nan point is in doubt already)
+    // both indices in [0, N): a negative one sets the sign bit of the OR
+    const bool in0 = (uint32_t)(ix0 | iz) < (uint32_t)LRM_TT_N, in1 = (uint32_t)(ix1 | iz) < (uint32_t)LRM_TT_N;
+    const uint32_t row = cbase + (uint32_t)(iz * LRM_TT_N);
+    const uint32_t a0 = row + (uint32_t)ix0, a1 = row + (uint32_t)ix1;
+    const uint32_t c0 = lrm_tt_cell(cells, in0 ? a0 : cbase), c1 = lrm_tt_cell(cells, in1 ? a1 : cbase);
+    // sub-cell inside a refined cell (fx - gx is in [0, 1), exactly)
+    const uint32_t sz = (uint32_t)(int)((fz - gz) * (float)LRM_TT_SUB) * (uint32_t)LRM_TT_SUB + fbase;
+    const uint32_t s0 = sz + (uint32_t)(int)((fx0 - gx0) * (float)LRM_TT_SUB), s1 = sz + (uint32_t)(int)((fx1 - gx1) * (float)LRM_TT_SUB);
+    const bool r0 = (c0 & 0x8000u) != 0u, r1 = (c1 & 0x8000u) != 0u;
+    const uint32_t b0 = ((c0 & 0x7fffu) << 8) + s0, b1 = ((c1 & 0x7fffu) << 8) + s1; // LRM_TT_SUB^2 = 256 entries per block
+    static_assert(LRM_TT_SUB * LRM_TT_SUB == 256, "fine block size");
+    const uint32_t f0 = lrm_tt_cell(cells, r0 ? b0 : fbase), f1 = lrm_tt_cell(cells, r1 ? b1 : fbase);
+    const uint32_t k0 = r0 ? f0 : c0, k1 = r1 ? f1 : c1;
+    code0 = in0 ? k0 : (uint32_t)LRM_TT_UNANSWERED;
+    code1 = in1 ? k1 : (uint32_t)LRM_TT_UNANSWERED;
 }
 // lrm_tol_plane restricted to what the cell's code names: at most two clamp targets, one circle's point validity.
-// Same arithmetic as lrm_tol_plane on those operands: for a point that no doubt bit sends to the bit-exact code the
-// result (du, dz, valid) is the one lrm_tol_plane gives.
-LRM_HD void lrm_tol_plane_tab(const LrmTolLeg& L, const LrmTolTabView G, uint32_t code, float u, float z, float band, float tau,
+// Same arithmetic as lrm_tol_plane on those operands.  x = abscissa - coxa_length.
+LRM_HD void lrm_tol_plane_tab(const LrmTolTabView& G, uint32_t code, float x, float z, float band, float tau,
                               float& du, float& dz, bool& valid, uint32_t& doubt) {
-    const float x = u - L.coxa_length;
     const LrmTabVRow vr = G.vrows[(code >> 10) & 31u];
     const LrmTabRow ra = G.rows[code & 31u], rb = G.rows[(code >> 5) & 31u];
     float vacc;
@@ -332,7 +321,8 @@ LRM_HD void lrm_tol_plane_tab(const LrmTolLeg& L, const LrmTolTabView G, uint32_
     const bool wina = ka <= kb;
     const float lo2 = wina ? ka : kb, hi2 = wina ? kb : ka;
     // |b - a| < tau  <=>  b^2 < a^2 + tau (2a + tau), with the relative allowance of lrm_tol_plane's ranking keys
-    const float a = LRM_FAST_SQRT(lo2);
+    // (the winner's distance itself is |r - mag|; when even the winner is an invalid clamp, lo2 is huge and the point in doubt)
+    const float a = fabsf(wina ? da : db);
     const float tie_thr = __builtin_fmaf(lo2, 4.0e-6f, __builtin_fmaf(tau, __builtin_fmaf(2.0f, a, tau), lo2));
     const float vx = wina ? ax : bx, vy = wina ? ay : by, m = wina ? ma : mb, rs = wina ? rsa : rsb, r = wina ? ra.r : rb.r;
     const float s = __builtin_fmaf(-r, rs, 1.0f);
@@ -343,8 +333,140 @@ LRM_HD void lrm_tol_plane_tab(const LrmTolLeg& L, const LrmTolTabView G, uint32_
     lu |= !(cacc > tau) ? LRM_TD_CLAMP : 0u;
     lu |= !(hi2 > tie_thr) ? LRM_TD_TIE : 0u;
     lu |= (!(lo2 < 1.0e30f) || !(m * LRM_TOL_AMP2 > r * r)) ? LRM_TD_NONE : 0u;
-    lu |= (code == (uint32_t)LRM_TT_UNANSWERED || !(band <= G.band_max)) ? LRM_TD_AMBIG : 0u;
+    lu |= (code == (uint32_t)LRM_TT_UNANSWERED) ? LRM_TD_AMBIG : 0u;
     doubt |= lu;
+}
+
+// The whole evaluation of one point with the table: distance_global + reachability_global (one_leg_global.cu:74-130).
+// The flow of lrm_tol_prologue / lrm_tol_candidate / lrm_tol_need_second / lrm_tol_finish, written as one function so
+// that a candidate is carried as (code, du, w, dz) -- the rotation back to the coxa frame is formed once, for the
+// candidate that wins -- and its plane abscissa is selected from (+-r, uM, um) instead of rotated.
+// p: in = the point, out = the distance vector.  Returns the reach / validity flag.  doubt != 0: do not use the outputs.
+LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p, uint32_t& doubt) {
+    const float* a = L.aff;
+    const float x = __builtin_fmaf(a[0], p.x, __builtin_fmaf(a[1], p.y, __builtin_fmaf(a[2], p.z, a[3])));
+    const float y = __builtin_fmaf(a[4], p.x, __builtin_fmaf(a[5], p.y, __builtin_fmaf(a[6], p.z, a[7])));
+    const float z = __builtin_fmaf(a[8], p.x, __builtin_fmaf(a[9], p.y, __builtin_fmaf(a[10], p.z, a[11])));
+    // non-finite input: the band is nan/inf and every "> band" test fails closed (doubt)
+    const float band = __builtin_fmaf(fabsf(p.x) + fabsf(p.y) + fabsf(p.z), L.band_slope, L.band_base);
+    const float tau = band * LRM_TOL_TIE;
+    const float m2 = __builtin_fmaf(y, y, x * x);
+    const float rs = LRM_FAST_RSQ(m2);
+    const float r = m2 * rs;
+    const float cu = x * rs, su = y * rs; // cos / sin of the point's yaw
+    const float cM = L.yaw_cs[0], sM = L.yaw_cs[1], cm = L.yaw_cs[2], sm = L.yaw_cs[3];
+    const float uM = __builtin_fmaf(x, cM, y * sM), wM = __builtin_fmaf(y, cM, -(x * sM));
+    const float um = __builtin_fmaf(x, cm, y * sm), wm = __builtin_fmaf(y, cm, -(x * sm));
+    const uint32_t pat = (lrm_f2u(wM) >> 31) | ((lrm_f2u(uM) >> 30) & 2u) | ((lrm_f2u(wm) >> 29) & 4u) |
+                         ((lrm_f2u(um) >> 28) & 8u);
+    constexpr uint32_t kLutD = lrm_tol_lut(false), kLutF = lrm_tol_lut(true);
+    const uint32_t codeD = (kLutD >> (pat << 1)) & 3u, codeF = (kLutF >> (pat << 1)) & 3u;
+    const bool inD = (pat & 5u) == 1u, inF = (pat & 5u) == 4u;
+    const float ymin = lrm_min3_aa(wm, um, lrm_min3_aa(wM, uM, 3.0e38f));
+    uint32_t lu = (!(ymin > band) || !(r > LRM_TOL_RMIN) || !(band <= G.band_max)) ? LRM_TD_YAW : 0u;
+    const bool two = codeD != codeF;
+    // plane point of a candidate kind: abscissa {r, -r, uM, um}[code], offset {0, 0, wM, wm}[code].  Every `?:` below
+    // selects between values that exist already: straight-line v_cndmask code, no branches.
+    const bool limD = codeD >= 2u, limF = codeF >= 2u;
+    const float wlD = (codeD == 3u) ? wm : wM, wlF = (codeF == 3u) ? wm : wM;
+    const float wD = limD ? wlD : 0.f, wF = limF ? wlF : 0.f;
+    const bool nearD = fabsf(wD) <= fabsf(wF);
+    const bool firstD = inD || (!inF && nearD); // a candidate inside the yaw range goes first, else the nearer plane
+    const uint32_t code0 = firstD ? codeD : codeF, code1 = firstD ? codeF : codeD;
+    const float w0 = firstD ? wD : wF, w1 = firstD ? wF : wD;
+    const bool lim0 = code0 >= 2u, lim1 = code1 >= 2u;
+    const float ul0 = (code0 == 3u) ? um : uM, ul1 = (code1 == 3u) ? um : uM;
+    const float ur0 = lrm_u2f(lrm_f2u(r) ^ (code0 << 31)), ur1 = lrm_u2f(lrm_f2u(r) ^ (code1 << 31));
+    const float u0 = lim0 ? ul0 : ur0, u1 = lim1 ? ul1 : ur1;
+    const bool in0 = inD || inF;
+    // Both plane points lie within max(r + coxa_length, |z|) of the femur joint: one grid for both look-ups -- and for the whole
+    // wave (the outer grid covers the inner one's area too, with coarser cells): the choice lives on the scalar unit.
+    const bool far = LRM_TOL_ANY(!(fmaxf(r + L.coxa_length, fabsf(z)) < G.far_limit));
+    const float inv = far ? G.inv_h[1] : G.inv_h[0];
+    const uint32_t cbase = far ? G.coarse_off[1] : G.coarse_off[0], fbase = far ? G.fine_off[1] : G.fine_off[0];
+    const float x0 = u0 - L.coxa_length, x1 = u1 - L.coxa_length;
+    uint32_t cell0, cell1;
+    lrm_toltab_lookup2(G.cells, inv, cbase, fbase, x0, x1, z, cell0, cell1);
+    // ---- first candidate ----
+    float du0, dz0;
+    bool valid0;
+    lrm_tol_plane_tab(G, cell0, x0, z, band, tau, du0, dz0, valid0, lu);
+    // A candidate clamped to a yaw limit whose plane point is valid collapses to the offset from that plane, unless
+    // sqrt(du^2 + w^2 + dz^2) rounds to |w| (see lrm_dist_tol_t): q / w^2 above 2^-20 collapses, below 2^-25 stays, between: doubt
+    {
+        const float q = __builtin_fmaf(du0, du0, dz0 * dz0), w2 = w0 * w0;
+        const bool lv = lim0 && valid0, big = q > w2 * 9.6e-7f, small = q < w2 * 2.9e-8f;
+        const bool collapse = lv && big;
+        du0 = collapse ? 0.f : du0;
+        dz0 = collapse ? 0.f : dz0;
+        lu |= (lv && !big && !small) ? LRM_TD_LIMIT : 0u;
+    }
+    const float n0 = __builtin_fmaf(du0, du0, __builtin_fmaf(w0, w0, dz0 * dz0));
+    const bool flag = valid0 && in0;
+    // ---- the second one only when it can still win (lrm_tol_need_second) ----
+    bool need;
+    {
+        const float out = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(x1, x1, z * z)) - L.r_outer, 0.f);
+        const float lb = __builtin_fmaf(w1, w1, out * out);
+        const float thr = tau * __builtin_fmaf(2.0f, LRM_FAST_SQRT(n0), tau);
+        need = two && !flag && !(n0 < lb - thr);
+    }
+    float du1 = 0.f, dz1 = 0.f, n1 = 0.f;
+    if (LRM_TOL_ANY(need)) { // device: unless no lane of the wave needs it (a sorted cloud); host: when this point does
+        bool valid1;
+        uint32_t bd = 0;
+        lrm_tol_plane_tab(G, cell1, x1, z, band, tau, du1, dz1, valid1, bd);
+        const float q = __builtin_fmaf(du1, du1, dz1 * dz1), w2 = w1 * w1;
+        const bool lv = lim1 && valid1, big = q > w2 * 9.6e-7f, small = q < w2 * 2.9e-8f;
+        const bool collapse = lv && big;
+        du1 = collapse ? 0.f : du1;
+        dz1 = collapse ? 0.f : dz1;
+        bd |= (lv && !big && !small) ? LRM_TD_LIMIT : 0u;
+        n1 = __builtin_fmaf(du1, du1, __builtin_fmaf(w1, w1, dz1 * dz1));
+        lu |= need ? bd : 0u;
+    }
+    // ---- yaw-limit alternative (one_leg.cu:258-274) of a valid first candidate: the nearer limit plane wins when it is closer ----
+    uint32_t codeW;
+    float duW, wW, dzW;
+    {
+        const float aM = fabsf(wM), am = fabsf(wm);
+        const float dl = fminf(aM, am), dl2 = dl * dl;
+        const float thr = tau * __builtin_fmaf(2.0f, dl, tau);
+        // in doubt: the two distances tie, or the alternative is (or may be) taken and the two limit planes tie
+        const bool tie = !(fabsf(n0 - dl2) > thr) || (!(n0 < dl2 - thr) && !(fabsf(aM - am) > tau));
+        lu |= (flag && tie) ? LRM_TD_LIMIT : 0u;
+        const bool alt = flag && (n0 > dl2);
+        const bool useM = aM < am;
+        const uint32_t codeL = useM ? 2u : 3u;
+        const float wL = useM ? wM : wm;
+        codeW = alt ? codeL : code0;
+        duW = alt ? 0.f : du0;
+        dzW = alt ? 0.f : dz0;
+        wW = alt ? wL : w0;
+    }
+    // ---- distance_circles' pick (one_leg.cu:334): both invalid here (a valid first candidate never asks for the second): the shorter one ----
+    {
+        const float nmin = LRM_FAST_SQRT(fminf(n0, n1));
+        const float thr = tau * __builtin_fmaf(2.0f, nmin, tau);
+        lu |= (need && !(fabsf(n0 - n1) > thr)) ? LRM_TD_PICK : 0u;
+        const bool useB = need && !(n0 < n1);
+        codeW = useB ? code1 : codeW;
+        duW = useB ? du1 : duW;
+        wW = useB ? w1 : wW;
+        dzW = useB ? dz1 : dzW;
+    }
+    // ---- back: rotate by the winner's yaw, then to the caller's frame ----
+    const float cl = (codeW == 3u) ? cm : cM, sl = (codeW == 3u) ? sm : sM;
+    const float cr = lrm_u2f(lrm_f2u(cu) ^ (codeW << 31)), sr = lrm_u2f(lrm_f2u(su) ^ (codeW << 31));
+    const bool limW = codeW >= 2u;
+    const float c = limW ? cl : cr, s = limW ? sl : sr;
+    const float vx = __builtin_fmaf(duW, c, -(wW * s)), vy = __builtin_fmaf(duW, s, wW * c), vz = dzW;
+    const float* b = L.back;
+    p.x = __builtin_fmaf(b[0], vx, __builtin_fmaf(b[1], vy, b[2] * vz));
+    p.y = __builtin_fmaf(b[3], vx, __builtin_fmaf(b[4], vy, b[5] * vz));
+    p.z = __builtin_fmaf(b[6], vx, __builtin_fmaf(b[7], vy, b[8] * vz));
+    doubt |= lu;
+    return flag;
 }
 
 // distance_global + reachability_global (one_leg_global.cu:74-130) of one body-frame point.
@@ -642,24 +764,4 @@ LRM_HD bool lrm_dist_tol(const LrmTolLeg& L, const LrmTolTables T, LrmVec3& p, u
 #endif
     doubt |= lu;
     return lrm_tol_finish(L, S, A, need, B, p, doubt);
-}
-// the staged evaluation with the plane table (deferred decisions) in place of lrm_tol_plane
-LRM_HD bool lrm_dist_toltab(const LrmTolLeg& L, const LrmTolTabView G, LrmVec3& p, uint32_t& doubt) {
-    const LrmTolPoint S = lrm_tol_prologue(L, p);
-    uint32_t lu = S.lu;
-    float du, dz;
-    bool valid;
-    lrm_tol_plane_tab(L, G, lrm_toltab_lookup(G, S.u0 - L.coxa_length, S.z), S.u0, S.z, S.band, S.tau, du, dz, valid, lu);
-    const LrmTolCand A = lrm_tol_candidate(S, false, du, dz, valid, lu);
-    LrmTolCand B = A;
-    const bool need = lrm_tol_need_second(L, S, A);
-    if (need) {
-        lrm_tol_plane_tab(L, G, lrm_toltab_lookup(G, S.u1 - L.coxa_length, S.z), S.u1, S.z, S.band, S.tau, du, dz, valid, lu);
-        B = lrm_tol_candidate(S, true, du, dz, valid, lu);
-    }
-    doubt |= lu;
-    return lrm_tol_finish(L, S, A, need, B, p, doubt);
-}
-LRM_HD bool lrm_dist_tolgrid(const LrmTolLeg& L, const LrmTolTables T, const LrmTolGridView G, LrmVec3& p, uint32_t& doubt) {
-    return lrm_dist_tol_t(L, LrmTolPlaneGrid{L, T, G}, p, doubt);
 }

@@ -45,9 +45,6 @@
 #ifndef LRM_TOL_SEG_PER_WAVE
 #define LRM_TOL_SEG_PER_WAVE 8 // segments one fix-up workgroup compacts: ~20 queued points at the usual 0.4 % of doubt, one pass of its first wave
 #endif
-#ifndef LRM_TOL_SEG_CAP
-#define LRM_TOL_SEG_CAP 128 // doubt slots per workgroup (768 points): 17 %.  32 overflowed on the reference's planar bench grid (7 % in doubt: it contains the coxa axis and the symmetry plane)
-#endif
 #ifndef LRM_TOL_PREFETCH
 #define LRM_TOL_PREFETCH 1
 #endif
@@ -79,7 +76,6 @@ constexpr int kBlock = LRM_TOL_BLOCK;
 #endif
 constexpr int kFixBlock = LRM_TOL_FIX_BLOCK; // threads of a fix-up workgroup: with the usual handful of queued points only its first wave works,
                                              // a cloud that hugs decision boundaries (the planar bench grid: 7 % in doubt) keeps all of them busy
-constexpr int kMidBlock = 64;                // tol_mid_kernel (plane-table variant): one wave
 constexpr int kSegCap = LRM_TOL_SEG_CAP;         // doubt slots per workgroup of dist_tol_kernel
 constexpr int kSegPerWave = LRM_TOL_SEG_PER_WAVE;                 // segments one fix-up wave compacts
 
@@ -363,7 +359,7 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
 // the L2; its rows (1.5 KB) are staged in LDS.
 // ------------------------------------------------------------------------------------------------------------
 #ifndef LRM_TAB_MIN_WAVES
-#define LRM_TAB_MIN_WAVES 8
+#define LRM_TAB_MIN_WAVES 7 // 66 VGPRs: at 8 waves (64) the compiler spills 24 B per lane
 #endif
 #ifndef LRM_TAB_GRID_MULT
 #define LRM_TAB_GRID_MULT 8
@@ -382,7 +378,7 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
     __shared__ uint32_t s_qn;
     const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
-    LrmVec3 p_next{0.f, 0.f, 0.f};
+    LrmVec3 p_next{0.f, 0.f, 0.f}; // the first point in front of the table staging
     {
         const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x;
         const size_t rb0 = (size_t)blockIdx.x * kBlock;
@@ -397,8 +393,7 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
         if (threadIdx.x == 0) s_qn = 0;
         __syncthreads();
     }
-    const uint16_t* coarse = reinterpret_cast<const uint16_t*>(tab + sizeof(LrmTolTabHeader));
-    const LrmTolTabView G{s_tab.rows, s_tab.vrows, coarse, coarse + (size_t)LRM_TT_N * LRM_TT_N, hd->band_max};
+    const LrmTolTabView G = lrm_toltab_view(tab, s_tab.rows, s_tab.vrows);
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t n_pad = (uint32_t)((n + 63) & ~(size_t)63); // whole waves iterate together (ballots below)
     uint32_t* seg = queue + (size_t)blockIdx.x * kSegCap;
@@ -410,32 +405,15 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
         const size_t rbase = (size_t)blockIdx.x * kBlock + (size_t)round * stride;
         const uint32_t toff = lrm_opaque(toff0), tid_o = lrm_opaque(threadIdx.x);
         LrmVec3 p = p_next;
-        const LrmTolPoint S = lrm_tol_prologue(L, p);
-        // both cells first: the two look-ups (two dependent loads each) are in flight together
-        const uint32_t code0 = lrm_toltab_lookup(G, S.u0 - L.coxa_length, S.z);
-        const uint32_t code1 = lrm_toltab_lookup(G, S.u1 - L.coxa_length, S.z);
-        {
+        {   // the next round's point is in flight while this one is evaluated
             const uint32_t i_next = i + stride;
             const size_t rb_next = rbase + stride;
             p_next = LrmVec3{0.f, 0.f, 0.f};
             if (i_next < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
                                           : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
         }
-        uint32_t lu = S.lu;
-        float du, dzz;
-        bool valid;
-        lrm_tol_plane_tab(L, G, code0, S.u0, S.z, S.band, S.tau, du, dzz, valid, lu);
-        const LrmTolCand A = lrm_tol_candidate(S, false, du, dzz, valid, lu);
-        const bool need = live && lrm_tol_need_second(L, S, A);
-        LrmTolCand B = A;
-        if (__any(need)) { // a random cloud: always; a sorted one: a quarter of its waves
-            uint32_t bd = 0;
-            lrm_tol_plane_tab(L, G, code1, S.u1, S.z, S.band, S.tau, du, dzz, valid, bd);
-            B = lrm_tol_candidate(S, true, du, dzz, valid, bd);
-            lu |= need ? bd : 0u;
-        }
-        uint32_t doubt = lu;
-        const bool m = lrm_tol_finish(L, S, A, need, B, p, doubt) && live;
+        uint32_t doubt = 0;
+        const bool m = lrm_tab_point(L, G, p, doubt) && live;
         doubt = live ? (doubt & 0xffffu) : 0u;
         if (live) {
             if (kAoS) {
@@ -657,180 +635,6 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Plane-table variant (lrm_types.h LrmTolGridHeader, lrm_tolgrid.cpp): three launches.
-//   dist_tolgrid_kernel  every point: prologue + per candidate ONE table lookup (two LDS reads) and the winner's
-//                        clamp.  The table (32 KB coarse + 16 B per refined cell) is staged in LDS per workgroup,
-//                        so the grid is exactly the resident workgroups and strides over the cloud.  A point with
-//                        an unanswered cell or any decision in doubt goes to its WAVE's segment of queue A (slot
-//                        numbers from the wave's own counter: no atomics of any kind).
-//   tol_mid_kernel       one wave per segment of queue A: the full tolerance evaluation (lrm_dist_tol) of those
-//                        points (~7 %), outputs overwritten; ITS doubts go to the wave's segment of queue B.
-//   tol_fixup_kernel     queue B (~0.5 %) through the bit-exact code, as above.
-// Segments hold as many slots as their wave sees points: nothing can overflow.
-// ------------------------------------------------------------------------------------------------------------
-#ifndef LRM_TOLGRID_MERGED
-#define LRM_TOLGRID_MERGED 2 // 2: the full evaluation of the unanswered points runs inside dist_tolgrid_kernel as soon as 64 are queued; 1: at its end; 0: in tol_mid_kernel
-#endif
-#ifndef LRM_TOLGRID_BLOCK
-#define LRM_TOLGRID_BLOCK 512
-#endif
-#ifndef LRM_TOLGRID_MIN_WAVES
-#define LRM_TOLGRID_MIN_WAVES 6
-#endif
-constexpr int kGridBlock = LRM_TOLGRID_BLOCK;
-
-template <int kOp>
-__global__ __launch_bounds__(kGridBlock, LRM_TOLGRID_MIN_WAVES) void dist_tolgrid_kernel(
-    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
-    const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
-    float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ grid, uint32_t grid_bytes,
-    uint32_t* __restrict__ queue_a, uint32_t* __restrict__ counts_a, uint32_t* __restrict__ queue_b,
-    uint32_t* __restrict__ counts_b, uint32_t seg_cap) {
-    __shared__ TolLds s_tab;
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_grid[]; // coarse | fine (the header stays in global memory)
-    const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
-    {
-        const float* csrc = reinterpret_cast<const float*>(&L.circ[0][0]);
-        const float* fsrc = reinterpret_cast<const float*>(&L.feat[0]);
-        for (int i = threadIdx.x; i < (int)(sizeof(s_tab.circ) / 4); i += kGridBlock) reinterpret_cast<float*>(s_tab.circ)[i] = csrc[i];
-        for (int i = threadIdx.x; i < (int)(sizeof(s_tab.feat) / 4); i += kGridBlock) reinterpret_cast<float*>(s_tab.feat)[i] = fsrc[i];
-        const uint4* gsrc = reinterpret_cast<const uint4*>(grid + sizeof(LrmTolGridHeader));
-        const uint32_t n16 = (grid_bytes - (uint32_t)sizeof(LrmTolGridHeader)) >> 4;
-        for (uint32_t i = threadIdx.x; i < n16; i += kGridBlock) reinterpret_cast<uint4*>(s_grid)[i] = gsrc[i];
-        __syncthreads();
-    }
-    const LrmTolTables T{s_tab.circ, s_tab.feat};
-    const LrmTolGridView G{reinterpret_cast<const uint16_t*>(s_grid), s_grid + (size_t)LRM_TG_N * LRM_TG_N * 2,
-                           reinterpret_cast<const LrmTolGridHeader*>(grid)->band_max};
-    const size_t stride = (size_t)gridDim.x * kGridBlock;
-    const size_t n_pad = (n + 63) & ~(size_t)63;
-    const uint32_t wave = blockIdx.x * (kGridBlock / 64) + (threadIdx.x >> 6);
-    uint32_t* seg = queue_a + (size_t)wave * seg_cap;
-    const int lane = threadIdx.x & 63;
-    uint32_t cnt = 0; // wave-uniform
-    uint32_t* seg_b = queue_b + (size_t)wave * seg_cap;
-    uint32_t cnt_b = 0, done = 0;
-    // The full evaluation of 64 queued points (about 7 % of the points end up here).  Run as soon as a batch is
-    // full: the scattered 4-byte reads and writes then hit lines this wave touched a few iterations ago (still in
-    // the L2 / Infinity Cache); at the end of the kernel they are partial-line read-modify-writes in HBM and cost
-    // as much as the whole dense pass (65 us for 7e5 points, in a launch of its own or as a tail).
-    auto full_batch = [&](uint32_t k0, uint32_t kend) {
-        const uint32_t k = k0 + (uint32_t)lane;
-        uint32_t doubt = 0;
-        size_t j = 0;
-        if (k < kend) {
-            j = seg[k];
-            LrmVec3 p{x[j], y[j], z[j]};
-            const bool m = lrm_dist_tol(L, T, p, doubt);
-            doubt &= 0xffffu;
-            dx[j] = p.x;
-            dy[j] = p.y;
-            dz[j] = p.z;
-            if (mask) mask[j] = m;
-            if (bits) patch_bit(bits, j, m);
-        }
-        const uint64_t dm = __ballot(doubt != 0);
-        if (doubt) seg_b[cnt_b + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)j;
-        cnt_b += (uint32_t)__popcll(dm);
-    };
-    size_t i = (size_t)blockIdx.x * kGridBlock + threadIdx.x;
-    // The next iteration's coordinates are in flight while this one computes.  (Two points per lane and iteration,
-    // to overlap the dependent LDS lookups of two chains, was slower: 87 us against 79 -- the kernel is bound by
-    // VALU issue, 70 % of its instructions being half-rate selects, compares and 64-bit address arithmetic.)
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (i < n) { nx = x[i]; ny = y[i]; nz = z[i]; }
-    for (; i < n_pad; i += stride) {
-        LrmVec3 p{nx, ny, nz};
-        const size_t inext = i + stride;
-        if (inext < n) { nx = x[inext]; ny = y[inext]; nz = z[inext]; }
-        bool m = false;
-        uint32_t doubt = 0;
-        if (i < n) {
-#if defined(LRM_TOLGRID_COPYONLY) // experiment: the memory access pattern alone (40 us per 1e7 points: 6.2 TB/s)
-            m = p.x > 300.f;
-            p.x += 1.f;
-#else
-            m = lrm_dist_tolgrid(L, T, G, p, doubt);
-#endif
-            doubt &= 0xffffu;
-            dx[i] = p.x;
-            dy[i] = p.y;
-            dz[i] = p.z;
-            if (mask) mask[i] = m;
-        }
-        if (bits) {
-            const uint64_t w = __ballot(m);
-            if (lane == 0) bits[i >> 6] = w;
-        }
-        const uint64_t dm = __ballot(doubt != 0);
-        if (doubt) seg[cnt + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)i;
-        cnt += (uint32_t)__popcll(dm);
-#if LRM_TOLGRID_MERGED == 2
-        if (cnt - done >= 64u) { // wave-uniform
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the queue entries and this wave's outputs have landed
-            full_batch(done, done + 64u);
-            done += 64u;
-        }
-#endif
-    }
-    if (lane == 0) counts_a[wave] = cnt; // statistic (lrm_dbg_tol_queue_counts)
-#if LRM_TOLGRID_MERGED
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (; done < cnt; done += 64u) full_batch(done, cnt);
-    if (lane == 0) counts_b[wave] = cnt_b;
-#endif
-}
-
-// one wave per segment of queue A
-template <int kOp>
-__global__ __launch_bounds__(kMidBlock) void tol_mid_kernel(
-    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
-    const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
-    float* __restrict__ dy, float* __restrict__ dz, const uint32_t* __restrict__ queue_a,
-    const uint32_t* __restrict__ counts_a, uint32_t* __restrict__ queue_b, uint32_t* __restrict__ counts_b,
-    uint32_t seg_cap) {
-    __shared__ TolLds s_tab;
-    const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
-    const uint32_t total = counts_a[blockIdx.x];
-    const int lane = threadIdx.x;
-    if (total == 0) {
-        if (lane == 0) counts_b[blockIdx.x] = 0;
-        return;
-    }
-    {
-        const float* csrc = reinterpret_cast<const float*>(&L.circ[0][0]);
-        const float* fsrc = reinterpret_cast<const float*>(&L.feat[0]);
-        for (int i = lane; i < (int)(sizeof(s_tab.circ) / 4); i += kMidBlock) reinterpret_cast<float*>(s_tab.circ)[i] = csrc[i];
-        for (int i = lane; i < (int)(sizeof(s_tab.feat) / 4); i += kMidBlock) reinterpret_cast<float*>(s_tab.feat)[i] = fsrc[i];
-        __syncthreads();
-    }
-    const LrmTolTables T{s_tab.circ, s_tab.feat};
-    const uint32_t* seg_a = queue_a + (size_t)blockIdx.x * seg_cap;
-    uint32_t* seg_b = queue_b + (size_t)blockIdx.x * seg_cap;
-    uint32_t cnt = 0;
-    for (uint32_t k0 = 0; k0 < total; k0 += kMidBlock) { // whole wave iterates together (ballot below)
-        const uint32_t k = k0 + lane;
-        uint32_t doubt = 0;
-        size_t i = 0;
-        if (k < total) {
-            i = seg_a[k];
-            LrmVec3 p{x[i], y[i], z[i]};
-            const bool m = lrm_dist_tol(L, T, p, doubt);
-            doubt &= 0xffffu;
-            dx[i] = p.x;
-            dy[i] = p.y;
-            dz[i] = p.z;
-            if (mask) mask[i] = m;
-            if (bits) patch_bit(bits, i, m);
-        }
-        const uint64_t dm = __ballot(doubt != 0);
-        if (doubt) seg_b[cnt + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)i;
-        cnt += (uint32_t)__popcll(dm);
-    }
-    if (lane == 0) counts_b[blockIdx.x] = cnt;
-}
-
 } // namespace
 
 // Workgroups of the main kernel for n points: every resident slot LRM_TOL_GRID_MULT times over, and for larger clouds as many
@@ -932,68 +736,4 @@ hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const Lrm
     (void)op; (void)xyz; (void)n; (void)L; (void)TL; (void)mask; (void)dxyz; (void)workspace; (void)st;
     return hipErrorNotSupported;
 #endif
-}
-
-// ---- plane-table variant ------------------------------------------------------------------------------------
-namespace {
-// resident workgroups per CU of dist_tolgrid_kernel for a table of `dyn` bytes of dynamic LDS, as the runtime
-// sees it (LDS granularity, registers, wave slots); cached per table size
-int tolgrid_blocks_per_cu(size_t dyn) {
-    static size_t cached_dyn = ~(size_t)0;
-    static int cached = 1;
-    if (dyn != cached_dyn) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dist_tolgrid_kernel<2>, kGridBlock, dyn) != hipSuccess || nb < 1) {
-            (void)hipGetLastError();
-            nb = 1;
-        }
-        cached = nb;
-        cached_dyn = dyn;
-        if (getenv("LRM_TOL_DEBUG")) fprintf(stderr, "dist_tolgrid_kernel: %d workgroups of %d per CU with %zu B of dynamic LDS\n", nb, kGridBlock, dyn);
-    }
-    return cached;
-}
-} // namespace
-
-void lrm_tolgrid_plan(size_t n, size_t grid_bytes, uint32_t* blocks_out, uint32_t* seg_cap_out, size_t* workspace_words_out) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    size_t blocks = (size_t)cus * tolgrid_blocks_per_cu(grid_bytes - sizeof(LrmTolGridHeader));
-    const size_t need = (n + kGridBlock - 1) / kGridBlock;
-    if (blocks > need) blocks = need ? need : 1;
-    const size_t stride = blocks * kGridBlock;
-    const size_t iters = (((n + 63) & ~(size_t)63) + stride - 1) / stride;
-    const size_t seg_cap = iters * 64;
-    const size_t waves = blocks * (kGridBlock / 64);
-    *blocks_out = (uint32_t)blocks;
-    *seg_cap_out = (uint32_t)seg_cap;
-    *workspace_words_out = 2 * waves * seg_cap + 2 * waves; // queue A, queue B, counts A, counts B
-}
-
-hipError_t lrm_launch_dist_tolgrid(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
-                                   const LrmTolLeg& TL, const uint8_t* grid_dev, size_t grid_bytes, uint8_t* mask,
-                                   uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace, hipStream_t st) {
-    uint32_t blocks = 0, seg_cap = 0;
-    size_t words = 0;
-    lrm_tolgrid_plan(n, grid_bytes, &blocks, &seg_cap, &words);
-    const size_t waves = (size_t)blocks * (kGridBlock / 64);
-    uint32_t* queue_a = workspace;
-    uint32_t* queue_b = queue_a + waves * seg_cap;
-    uint32_t* counts_a = queue_b + waves * seg_cap;
-    uint32_t* counts_b = counts_a + waves;
-    const size_t dyn = grid_bytes - sizeof(LrmTolGridHeader);
-    if (op == 2) hipLaunchKernelGGL(dist_tolgrid_kernel<2>, dim3(blocks), dim3(kGridBlock), dyn, st, x, y, z, n, TL, mask, bits, dx, dy, dz, grid_dev, (uint32_t)grid_bytes, queue_a, counts_a, queue_b, counts_b, seg_cap);
-    else hipLaunchKernelGGL(dist_tolgrid_kernel<1>, dim3(blocks), dim3(kGridBlock), dyn, st, x, y, z, n, TL, mask, bits, dx, dy, dz, grid_dev, (uint32_t)grid_bytes, queue_a, counts_a, queue_b, counts_b, seg_cap);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-#if !LRM_TOLGRID_MERGED
-    if (op == 2) hipLaunchKernelGGL(tol_mid_kernel<2>, dim3((unsigned)waves), dim3(kMidBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue_a, counts_a, queue_b, counts_b, seg_cap);
-    else hipLaunchKernelGGL(tol_mid_kernel<1>, dim3((unsigned)waves), dim3(kMidBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue_a, counts_a, queue_b, counts_b, seg_cap);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-#endif
-    const unsigned fblocks = (unsigned)((waves + kSegPerWave - 1) / kSegPerWave);
-    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue_b, counts_b, (uint32_t)waves, seg_cap, (size_t)0);
-    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue_b, counts_b, (uint32_t)waves, seg_cap, (size_t)0);
-    return hipGetLastError();
 }

@@ -18,13 +18,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 #include "lrm_compile.h"
 #include "lrm_point_tol.h"
 
 namespace {
 
-int g_reason = 0; // why the last cell went unanswered (statistics): 1 regions differ, 2 two open validities, 3 a centre nearby, 4 more than two targets, 5 none
+thread_local int g_reason = 0; // why the last cell went unanswered (statistics): 1 regions differ, 2 two open validities, 3 a centre nearby, 4 more than two targets, 5 none
 struct Rows {
     std::vector<LrmTabRow> rows;
     std::vector<LrmTabVRow> vrows;
@@ -124,8 +125,9 @@ CellCode classify_reg(const LrmTolLeg& L, unsigned reg, double cx, double cz, do
 
 bool same_row(const LrmTabRow& a, const LrmTabRow& b) { return std::memcmp(&a, &b, sizeof a) == 0; }
 
-// code of the cell, or LRM_TT_UNANSWERED
-unsigned classify_cell(const LrmTolLeg& L, Rows& R, double cx, double cz, double rho, double band, double tau) {
+// what the cell's points may be evaluated with, or !ok.  Where find_region's rays cross the cell, every region in
+// reach must give the same rows.
+CellCode classify_cell(const LrmTolLeg& L, double cx, double cz, double rho, double band, double tau) {
     double v[4];
     for (int i = 0; i < 3; i++) v[i] = (double)L.dir_cos[i] * cz - (double)L.dir_sin[i] * cx;
     v[3] = cz; // the atan2f wrap ray (x < 0, z = +-0) is the sign of z itself
@@ -141,7 +143,7 @@ unsigned classify_cell(const LrmTolLeg& L, Rows& R, double cx, double cz, double
         const unsigned reg = (L.region_lut >> (pat << 1)) & 3u;
         if (!(seen & (1u << reg))) {
             const CellCode c = classify_reg(L, reg, cx, cz, rho, band, tau);
-            if (!c.ok) return LRM_TT_UNANSWERED;
+            if (!c.ok) return c;
             if (!seen) code = c;
             else {
                 bool same = c.n == code.n && std::memcmp(&c.v, &code.v, sizeof c.v) == 0;
@@ -149,73 +151,126 @@ unsigned classify_cell(const LrmTolLeg& L, Rows& R, double cx, double cz, double
                 if (same && c.n == 2)
                     same = (same_row(c.t[0], code.t[0]) && same_row(c.t[1], code.t[1])) ||
                            (same_row(c.t[0], code.t[1]) && same_row(c.t[1], code.t[0]));
-                if (!same) { g_reason = 1; return LRM_TT_UNANSWERED; }
+                if (!same) {
+                    g_reason = 1;
+                    code.ok = false;
+                    return code;
+                }
             }
             seen |= 1u << reg;
         }
         if (sub == 0) break;
     }
-    const int a = R.row(code.t[0]), b = R.row(code.t[1]), vr = R.vrow(code.v);
-    if (a > LRM_TT_MAX_ROWS - 1 || b > LRM_TT_MAX_ROWS - 1 || vr > LRM_TT_MAX_ROWS - 1) return 0x10000u; // out of rows: no table for this leg
-    return (unsigned)a | ((unsigned)b << 5) | ((unsigned)vr << 10);
+    return code;
+}
+
+// One grid: N x N cells of H mm around the femur joint, unanswered cells refined into LRM_TT_SUB^2 sub-cells.
+// Rows of cells are classified on `threads` host threads (the cells are independent); row numbers are given
+// afterwards, serially, so that the table does not depend on the thread count.
+struct GridCells {
+    std::vector<CellCode> coarse;             // N * N
+    std::vector<std::vector<CellCode>> fine;  // per refined cell: SUB * SUB
+    std::vector<int> fine_of;                 // N * N: index into fine, or -1
+};
+void classify_grid(const LrmTolLeg& L, double H, double band, double tau, int threads, GridCells* out) {
+    constexpr int N = LRM_TT_N, kSub = LRM_TT_SUB;
+    const double half = 0.5 * N * H, h = H / kSub;
+    // The per-point code finds its cell from float arithmetic (one FMA + floor: off by at most 2^-17 of a cell) on a plane
+    // point that itself carries a few 1e-5 mm of rounding: the classification holds a margin around the cell.
+    const double slack = H * 1.6e-5 + 1.0e-3;
+    out->coarse.assign((size_t)N * N, CellCode());
+    out->fine_of.assign((size_t)N * N, -1);
+    std::vector<std::vector<CellCode>> fine_rows((size_t)N * N);
+    auto work = [&](int t) {
+        for (int iz = t; iz < N; iz += threads)
+            for (int ix = 0; ix < N; ix++) {
+                const double x0 = -half + ix * H, z0 = -half + iz * H;
+                CellCode c = classify_cell(L, x0 + 0.5 * H, z0 + 0.5 * H, 0.5 * H * 1.41421357 + slack, band, tau);
+                out->coarse[(size_t)iz * N + ix] = c;
+                if (c.ok) continue;
+                std::vector<CellCode> sub((size_t)kSub * kSub);
+                bool any = false;
+                for (int sz = 0; sz < kSub; sz++)
+                    for (int sx = 0; sx < kSub; sx++) {
+                        sub[(size_t)sz * kSub + sx] = classify_cell(L, x0 + (sx + 0.5) * h, z0 + (sz + 0.5) * h, 0.5 * h * 1.41421357 + slack, band, tau);
+                        any = any || sub[(size_t)sz * kSub + sx].ok;
+                    }
+                if (any) fine_rows[(size_t)iz * N + ix] = std::move(sub);
+            }
+    };
+    if (threads <= 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    for (size_t i = 0; i < fine_rows.size(); i++)
+        if (!fine_rows[i].empty()) {
+            out->fine_of[i] = (int)out->fine.size();
+            out->fine.push_back(std::move(fine_rows[i]));
+        }
 }
 
 } // namespace
 
-// -> false when the leg needs more distinct rows than a code can name (the caller then uses the kernels without a table)
+// -> false when the leg needs more distinct rows than a cell code can name (the caller then uses the kernels without a table)
 bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out) {
     // the largest decision band the table is built for: points up to |p|_1 = 4096 mm
     const double band = (double)L.band_base + (double)L.band_slope * 4096.0;
     const double tau = band * (double)LRM_TOL_TIE;
-    const double H = LRM_TT_H, h = H / (double)LRM_TT_SUB;
-    constexpr int kSub = LRM_TT_SUB;
+    constexpr int N = LRM_TT_N, kSub = LRM_TT_SUB;
+    int threads = (int)std::thread::hardware_concurrency();
+    threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads);
+    if (const char* e = std::getenv("LRM_TOLTAB_THREADS")) threads = std::max(1, std::atoi(e));
+    const double Hs[2] = {LRM_TT_H_INNER, LRM_TT_H_OUTER};
+    GridCells grids[2];
+    for (int g = 0; g < 2; g++) classify_grid(L, Hs[g], band, tau, threads, &grids[g]);
     Rows R;
     R.row(kNoneRow);   // row 0
-    R.vrow(kFalseRow); // vrow 0
-    R.vrow(kTrueRow);  // vrow 1
-    std::vector<uint16_t> coarse((size_t)LRM_TT_N * LRM_TT_N);
-    std::vector<uint16_t> fine;
-    size_t n_fine = 0, n_un = 0;
-    for (int iz = 0; iz < LRM_TT_N; iz++)
-        for (int ix = 0; ix < LRM_TT_N; ix++) {
-            const double x0 = -LRM_TT_HALF + ix * H, z0 = -LRM_TT_HALF + iz * H;
-            unsigned code = classify_cell(L, R, x0 + 0.5 * H, z0 + 0.5 * H, 0.5 * H * 1.41421357, band, tau);
-            if (code == 0x10000u) return false;
-            if (code == LRM_TT_UNANSWERED && n_fine < 0x7ffe) {
-                uint16_t sub[kSub * kSub];
-                bool any = false;
-                for (int sz = 0; sz < kSub; sz++)
-                    for (int sx = 0; sx < kSub; sx++) {
-                        const unsigned c = classify_cell(L, R, x0 + (sx + 0.5) * h, z0 + (sz + 0.5) * h, 0.5 * h * 1.41421357, band, tau);
-                        if (c == 0x10000u) return false;
-                        sub[sz * kSub + sx] = (uint16_t)c;
-                        any = any || c != LRM_TT_UNANSWERED;
-                    }
-                if (any) {
-                    fine.insert(fine.end(), sub, sub + kSub * kSub);
-                    coarse[(size_t)iz * LRM_TT_N + ix] = (uint16_t)(0x8000u | (unsigned)n_fine);
-                    n_fine++;
-                    continue;
-                }
-            }
-            if (code == LRM_TT_UNANSWERED) n_un++;
-            coarse[(size_t)iz * LRM_TT_N + ix] = (uint16_t)code;
-        }
+    R.vrow(kFalseRow); // validity rows 0, 1
+    R.vrow(kTrueRow);
+    bool rows_ok = true;
+    auto code_of = [&](const CellCode& c) -> uint16_t {
+        if (!c.ok) return (uint16_t)LRM_TT_UNANSWERED;
+        const int a = R.row(c.t[0]), b = R.row(c.t[1]), vr = R.vrow(c.v);
+        if (a > LRM_TT_MAX_ROWS - 1 || b > LRM_TT_MAX_ROWS - 1 || vr > LRM_TT_MAX_ROWS - 1) rows_ok = false;
+        return (uint16_t)(((unsigned)a & 31u) | (((unsigned)b & 31u) << 5) | (((unsigned)vr & 31u) << 10));
+    };
     LrmTolTabHeader hd;
     std::memset(&hd, 0, sizeof hd);
-    hd.n_fine = (uint32_t)n_fine;
+    std::vector<uint16_t> cells;
+    size_t n_un[2] = {0, 0};
+    for (int g = 0; g < 2; g++) {
+        const GridCells& G = grids[g];
+        if (G.fine.size() > 0x7fff) return false;
+        hd.coarse_off[g] = (uint32_t)cells.size();
+        for (size_t i = 0; i < (size_t)N * N; i++) {
+            if (G.fine_of[i] >= 0) cells.push_back((uint16_t)(0x8000u | (unsigned)G.fine_of[i]));
+            else {
+                cells.push_back(code_of(G.coarse[i]));
+                n_un[g] += !G.coarse[i].ok;
+            }
+        }
+        hd.fine_off[g] = (uint32_t)cells.size();
+        hd.n_fine[g] = (uint32_t)G.fine.size();
+        for (const auto& blk : G.fine)
+            for (const CellCode& c : blk) cells.push_back(code_of(c));
+        if (G.fine.empty()) cells.insert(cells.end(), (size_t)kSub * kSub, (uint16_t)LRM_TT_UNANSWERED); // the lookup reads block 0 for unrefined cells
+        hd.inv_h[g] = (float)(1.0 / Hs[g]);
+    }
+    if (!rows_ok) return false;
     hd.band_max = (float)band;
+    // both plane points of a point lie within max(r + coxa_length, |z|) of the femur joint (|u| <= r)
+    hd.far_limit = (float)(0.5 * N * Hs[0] - 1.0);
     hd.n_rows = (uint32_t)R.rows.size();
     hd.n_vrows = (uint32_t)R.vrows.size();
     for (size_t i = 0; i < 32; i++) hd.rows[i] = i < R.rows.size() ? R.rows[i] : kNoneRow;
     for (size_t i = 0; i < 32; i++) hd.vrows[i] = i < R.vrows.size() ? R.vrows[i] : kFalseRow;
-    fine.insert(fine.end(), (size_t)kSub * kSub, (uint16_t)LRM_TT_UNANSWERED); // one spare block: the lookup reads fine[0] for unrefined cells
-    out->resize(sizeof hd + coarse.size() * 2 + fine.size() * 2);
+    out->resize(sizeof hd + cells.size() * 2);
     std::memcpy(out->data(), &hd, sizeof hd);
-    std::memcpy(out->data() + sizeof hd, coarse.data(), coarse.size() * 2);
-    std::memcpy(out->data() + sizeof hd + coarse.size() * 2, fine.data(), fine.size() * 2);
+    std::memcpy(out->data() + sizeof hd, cells.data(), cells.size() * 2);
     if (std::getenv("LRM_TOL_DEBUG"))
-        std::fprintf(stderr, "tol tab: %zu rows, %zu validity rows, %zu refined cells, %zu coarse cells unanswered, %zu bytes\n",
-                     R.rows.size(), R.vrows.size(), n_fine, n_un, out->size());
+        std::fprintf(stderr, "tol tab: %zu rows, %zu validity rows; inner grid %u refined, %zu coarse cells unanswered; outer grid %u refined, %zu unanswered; %zu bytes\n",
+                     R.rows.size(), R.vrows.size(), hd.n_fine[0], n_un[0], hd.n_fine[1], n_un[1], out->size());
     return true;
 }

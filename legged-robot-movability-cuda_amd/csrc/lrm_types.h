@@ -161,50 +161,31 @@ struct LrmTolLeg {
     float pad_[2];
 };
 
-// ---- plane table of the tolerance mode (lrm_tolgrid.cpp, lrm_point_tol.h) ---------------------------------
-// Which clamp target wins (and whether the point is valid) is piecewise constant over the leg's meridian plane.
-// The table stores that answer per cell of a two-level grid over plane coordinates (x = abscissa - coxa_length, z):
-//   coarse: LRM_TG_N x LRM_TG_N cells of LRM_TG_H mm over [-LRM_TG_HALF, LRM_TG_HALF)^2, one uint16 each:
-//           < 64: the code of the whole cell;  0x8000 | b: refined into the 4 x 4 sub-cells of fine block b;
-//           0xffff: ambiguous and not refined (no room left)
-//   fine:   16 bytes per refined cell (row-major 4 x 4 sub-cells of LRM_TG_H / 4 mm): code, or 0xff = ambiguous
-//   code:   bits 0-4 the winning clamp target (index into LrmTolLeg::feat), bit 5 the validity of the point.
-// A cell carries a code only when EVERY decision of lrm_tol_plane keeps its margin over the whole cell for every
-// point with band <= band_max (Lipschitz bounds, lrm_tolgrid.cpp); anything else is "ambiguous" and is evaluated
-// in full.  Built on the host once per (leg, orientation), resident in device memory, staged in LDS per workgroup.
-#define LRM_TG_N 128
-#define LRM_TG_H 16.0f
-#define LRM_TG_HALF 1024.0f
-#define LRM_TG_AMBIG16 0xffffu
-#define LRM_TG_AMBIG8 0xffu
-struct LrmTolGridHeader {
-    uint32_t n_fine;      // refined cells (16 bytes each)
-    float band_max;       // the table holds for points whose decision band (mm) is at most this
-    uint32_t pad[2];
-};
-
 // ---- plane table with deferred decisions (lrm_toltab.cpp; lrm_point_tol.h: lrm_tol_plane_tab) -------------------
-// Second generation of the table above.  A cell no longer has to carry ONE answer: it names up to two clamp targets
+// Which clamp target wins (and whether the point is valid) is piecewise constant over the leg's meridian plane, so a
+// grid over plane coordinates (x = abscissa - coxa_length, z) can answer most plane evaluations.  (A first generation,
+// round 2, stored ONE answer per cell and left 7 % of the evaluations unanswered.)  Here a cell names up to two clamp targets
 // that can win anywhere in the cell and the one circle (if any) whose point validity is open over the cell; the
 // per-point code evaluates just those (a "reduced" lrm_tol_plane: same arithmetic on fewer operands, so the winner's
 // vector is the same float for float).  Everything else -- the region, the other circles' validity, the other clamp
 // targets, the arc tests of targets that are valid all over the cell -- is decided per cell on the host with
 // Lipschitz bounds.  With 16 mm cells refined once to 4 mm, 99.3 % of the plane evaluations of the config-2 cloud
 // are answered (the first-generation table: 92.8 %); the rest go to the bit-exact fix-up like any doubtful point.
-//   layout: LrmTolTabHeader | uint16 coarse[LRM_TT_N^2] | uint16 fine[LRM_TT_SUB^2 * (n_fine + 1)]
-//   coarse: bit 15 set (and not LRM_TT_UNANSWERED16): refined, bits 0-14 = fine block;  else a cell code
+//   layout: LrmTolTabHeader | uint16 cells[]: per grid (inner, outer) coarse[LRM_TT_N^2] and fine[LRM_TT_SUB^2 * max(n_fine, 1)]
+//   coarse: bit 15 set: refined, bits 0-14 = fine block;  else a cell code
 //   code (15 bits): target A (row, 5 bits) | target B (row, 5 bits) << 5 | validity row (5 bits) << 10;
 //                   LRM_TT_UNANSWERED = 0x7fff: no answer (rows 31 never exist)
 //   rows[]:  a clamp target {x, y, r, corner | mx, my, chw, bw}: `corner` = 3e38 for a corner point (it only competes when
 //            the point is invalid: one_leg.cu:109-116), 0 for a circle; the arc record as LrmTolLeg::Circle, with
 //            (1, 0, -2, 0) = "valid all over the cell".  Row 0 is NONE (never valid): the B slot of a one-target cell.
 //   vrows[]: point validity v = |p - (x, y)|^2 gs + c (valid <=> v < 0); rows 0 / 1 are the constants false / true.
-#define LRM_TT_N 128
-#define LRM_TT_H 16.0f
-#define LRM_TT_HALF 1024.0f
+#define LRM_TT_N 128           // coarse cells per axis, both grids
+#define LRM_TT_OFF 64.0f       // LRM_TT_N / 2: cell index = floor(coordinate / cell size + LRM_TT_OFF)
 #ifndef LRM_TT_SUB
-#define LRM_TT_SUB 16 // sub-cells per axis of a refined cell (1 mm): a fine block is LRM_TT_SUB^2 uint16
+#define LRM_TT_SUB 16          // sub-cells per axis of a refined cell: a fine block is LRM_TT_SUB^2 uint16
 #endif
+#define LRM_TT_H_INNER 16.0f   // inner grid: 16 mm cells (1 mm refined) over +-1024 mm around the femur joint
+#define LRM_TT_H_OUTER 128.0f  // outer grid: 128 mm cells (8 mm refined) over +-8192 mm: points the inner grid does not cover
 #define LRM_TT_UNANSWERED 0x7fffu
 #define LRM_TT_MAX_ROWS 31
 struct alignas(16) LrmTabRow {
@@ -215,8 +196,12 @@ struct alignas(16) LrmTabVRow {
     float x, y, gs, c;
 };
 struct LrmTolTabHeader {
-    uint32_t n_fine;   // refined cells (2 LRM_TT_SUB^2 bytes each)
-    float band_max;    // the table holds for points whose decision band (mm) is at most this
+    uint32_t n_fine[2];     // refined cells of the inner / outer grid (2 LRM_TT_SUB^2 bytes each)
+    uint32_t coarse_off[2]; // uint16 index, from the end of this header, of each grid's coarse array
+    uint32_t fine_off[2];   // ... of each grid's fine blocks (block 0 of a grid without refined cells is a spare)
+    float inv_h[2];         // 1 / cell size (mm)
+    float band_max;         // the table holds for points whose decision band (mm) is at most this
+    float far_limit;        // a point with max(r + coxa_length, |z|) below this has both plane points on the inner grid
     uint32_t n_rows, n_vrows;
     LrmTabRow rows[32];
     LrmTabVRow vrows[32];

@@ -140,6 +140,28 @@ def reach_any(bx, by, bz, tx, ty, tz, legs, quat=None, out=None, all_legs=None):
     return out, all_legs
 
 
+def positionability(bx, by, bz, tx, ty, tz, legs, quats, reference_culls=0, active=None, out=None):
+    """lrm_positionability_dev: the orientation sweep of robot_full_struct on device-resident clouds and masks.
+    reference_culls: 0 none, 2 the per-orientation cylinder culls.  -> (accepted uint8[nb] on the device, kernel ms)"""
+    import ctypes as C
+    torch = _torch()
+    nb = _check_f32(bx, by, bz)
+    nt = _check_f32(tx, ty, tz) if tx.numel() else 0
+    legs = np.ascontiguousarray(legs, dtype=np.float32).reshape(-1, 14)
+    quats = np.ascontiguousarray(quats, dtype=np.float32).reshape(-1, 4)
+    if out is None:
+        out = torch.empty(nb, dtype=torch.uint8, device=bx.device)
+    _check_out(out, bx, torch.uint8, nb, "accepted bytes")
+    _check_out(active, bx, torch.uint8, nb, "active bytes")
+    ms = C.c_float(0)
+    with torch.cuda.device(bx.device):
+        torch.cuda.synchronize(bx.device)  # the library works on the null stream
+        _capi.check(_capi.load().lrm_positionability_dev(_dp(bx), _dp(by), _dp(bz), nb, _dp(tx) if nt else None, _dp(ty) if nt else None,
+                                                         _dp(tz) if nt else None, nt, _capi._ptr(legs), len(legs), _capi._ptr(quats),
+                                                         len(quats), int(reference_culls), _dp(active), _dp(out), C.addressof(ms)))
+    return out, ms.value
+
+
 def any_in_sphere(cx, cy, cz, tx, ty, tz, radius, out=None):
     torch = _torch()
     nc = _check_f32(cx, cy, cz)

@@ -204,6 +204,66 @@ def _comm_device(dist, group):
     return "cuda" if (dist is not None and dist.get_backend(group) == "nccl") else "cpu"
 
 
+def _is_cuda(t):
+    return hasattr(t, "is_cuda") and t.is_cuda
+
+
+def _rows(t):
+    """(3, n) CUDA tensor -> its three component rows, each contiguous"""
+    return tuple(t[k].contiguous() for k in range(3))
+
+
+def _reduce_max_bytes(t, dist, group):
+    """all_reduce(MAX) of a uint8 CUDA tensor: in place over RCCL; through host memory for a CPU backend (gloo rehearsals)"""
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return t
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+    return h.to(t.device)
+
+
+def _positionability_sharded_dev(bodies, targets, legs, quats, reference_culls, group):
+    """positionability_sharded on device-resident clouds: (3, nb) and (3, nt) float32 CUDA tensors in, a uint8 CUDA tensor
+    [nb] out; the culls' masks, the all-reduce of the far-target cull, the compactions and the sweep all stay on the
+    device (RCCL reduces and gathers device memory; only a CPU backend stages the exchanged bytes through the host)."""
+    import torch
+    from . import device
+    dist, world, rank = _dist_info(group)
+    nb, nt = bodies.shape[1], targets.shape[1]
+    lo, hi = shard_bounds(nb, world, rank)
+    mine = bodies[:, lo:hi]
+    local = torch.zeros(hi - lo, dtype=torch.uint8, device=bodies.device)
+    legs = np.ascontiguousarray(np.asarray(legs, np.float32).reshape(-1, 14))
+    if hi > lo or (dist is not None and world > 1):
+        mx, my, mz = _rows(mine)
+        tx, ty, tz = _rows(targets)
+        if reference_culls and nt:
+            keep = torch.zeros(nt, dtype=torch.uint8, device=bodies.device)
+            alive = torch.zeros(hi - lo, dtype=torch.bool, device=bodies.device)
+            if hi > lo:
+                collide = device.any_in_sphere(mx, my, mz, tx, ty, tz, 60.0)   # eliminateAlwaysColliding
+                near = device.any_in_sphere(mx, my, mz, tx, ty, tz, 400.0)     # eliminateFarBody
+                alive = (collide == 0) & (near != 0)
+                if bool(alive.any()):
+                    ax, ay, az = (c[alive].contiguous() for c in (mx, my, mz))
+                    keep = device.any_in_sphere(tx, ty, tz, ax, ay, az, 400.0)
+            if dist is not None and world > 1:                                  # eliminateFarTarget over ALL ranks' survivors
+                keep = _reduce_max_bytes(keep, dist, group)
+            if bool(alive.any()):
+                sel = keep != 0
+                kx, ky, kz = (c[sel].contiguous() for c in (tx, ty, tz))
+                acc, _ = device.positionability(ax, ay, az, kx, ky, kz, legs, quats, 2)
+                local[alive] = acc
+        elif not reference_culls and hi > lo:
+            local, _ = device.positionability(mx, my, mz, tx, ty, tz, legs, quats, 0)
+    if dist is None or world == 1:
+        return local
+    if dist.get_backend(group) == "nccl":
+        return all_gather_bytes(local, nb, group)
+    return all_gather_bytes(local.cpu(), nb, group).to(bodies.device)
+
+
 def positionability_sharded(bodies, targets, legs, quats, reference_culls=False, backend=None, group=None):
     """robot_full_struct's result (lrm_positionability) with the BODIES split over the ranks: every rank holds all
     targets (1.2 MB for 1e5 points) and all legs, evaluates its contiguous slice of bodies, and the per-body bytes
@@ -212,8 +272,13 @@ def positionability_sharded(bodies, targets, legs, quats, reference_culls=False,
     With reference_culls the one-time culls of multi_rot_estimator (several_leg.cu:413-502) are evaluated here,
     because eliminateFarTarget keeps a target when ANY surviving body -- of any rank -- is within 400 mm: the
     per-rank keep masks are combined with all_reduce(MAX) (RCCL has no bitwise OR; max on 0/1 bytes is the same).
-    Without a process group this is the single-process composition of the same steps."""
+    Without a process group this is the single-process composition of the same steps.
+
+    bodies / targets: host arrays (n, 3) -> a host uint8 array; or float32 CUDA tensors (3, n) (SoA, as the *_dev entry
+    points take them) -> a uint8 CUDA tensor, with every intermediate mask kept on the device."""
     import torch
+    if _is_cuda(bodies) and _is_cuda(targets) and backend is None:
+        return _positionability_sharded_dev(bodies, targets, legs, quats, reference_culls, group)
     backend = backend or DeviceBackend()
     dist, world, rank = _dist_info(group)
     bodies = np.ascontiguousarray(np.asarray(bodies, np.float32).reshape(-1, 3))
@@ -245,10 +310,22 @@ def positionability_sharded(bodies, targets, legs, quats, reference_culls=False,
 def reach_any_target_sharded(bodies, local_targets, legs, quat=None, backend=None, group=None):
     """The any-flags of reach_mem_kernel (lrm_reach_any_dev) when the CLOUD is the big side (1e8 targets): every rank
     holds all bodies and its own slice of the targets; the per-(leg, body) bytes are combined with
-    all_reduce(MAX) and the AND over legs is taken locally.  Returns (out[leg, body], all_legs[body]) on every rank."""
+    all_reduce(MAX) and the AND over legs is taken locally.  Returns (out[leg, body], all_legs[body]) on every rank.
+
+    bodies / local_targets: host arrays (n, 3), or float32 CUDA tensors (3, n): then the flags never leave the device (the
+    target shard -- 150 MB for a 1.25e7-point share -- is used where it lies) and CUDA tensors come back."""
     import torch
-    backend = backend or DeviceBackend()
     dist, world, rank = _dist_info(group)
+    if _is_cuda(bodies) and _is_cuda(local_targets) and backend is None:
+        from . import device
+        legs_a = np.ascontiguousarray(np.asarray(legs, np.float32).reshape(-1, 14))
+        bx, by, bz = _rows(bodies)
+        tx, ty, tz = _rows(local_targets)
+        out, _ = device.reach_any(bx, by, bz, tx, ty, tz, legs_a, quat)
+        if dist is not None and world > 1:
+            out = _reduce_max_bytes(out.view(-1), dist, group).view(out.shape)
+        return out, out.min(dim=0).values
+    backend = backend or DeviceBackend()
     legs = np.ascontiguousarray(np.asarray(legs, np.float32).reshape(-1, 14))
     out = np.ascontiguousarray(backend.reach_any(bodies, local_targets, legs, quat).astype(np.uint8))
     if dist is not None and world > 1:

@@ -50,15 +50,51 @@ def in_box(v, h):
             (-h[0] < v[:, 0]) & (-h[1] < v[:, 1]) & (-h[2] < v[:, 2]))
 
 
-def apply_oct(oracle, footholds, dim, st):
-    footholds = np.ascontiguousarray(footholds, F).reshape(-1, 3)
-    n_angles_max = st.angle_sample[0] * st.angle_sample[1] * st.angle_sample[2]
-    quats = [quat_from_angle_index(oracle, a, st) for a in range(n_angles_max)]
+def octree_legs(dim, st):
     legs = []
     for l in range(st.leg_count):
         leg = np.array(dim, F).copy()
         leg[0] = F(st.leg_mount[l])
         legs.append(leg)
+    return legs
+
+
+def child_flags(oracle, footholds, c, h, parent_h, parent_valid, rot, st, legs, quats, reach_len):
+    """validity_child (several_leg_octree.cu:19-151) of ONE child box over the given footholds, with global ORs:
+    -> (reach_any, leaf_any, edge_any), the three flag bits csrc/lrm_octree.hip's kernels return per child."""
+    n_angles_max = st.angle_sample[0] * st.angle_sample[1] * st.angle_sample[2]
+    vect = (footholds - c).astype(F)
+    keep = in_box(vect, (parent_h + reach_len).astype(F))
+    vect = vect[keep]
+    reach_any = leaf_any = edge_any = False
+    if len(vect):
+        margin = F(0) if rot else F(F(st.enable_rot_below) / F(3))
+        h2 = F(F(h[0] * h[0] + h[1] * h[1]) + h[2] * h[2])
+        for a in range(n_angles_max if rot else 1):
+            reach_count = np.zeros(len(vect), int)
+            cross_count = np.zeros(len(vect), int)
+            for leg in legs:
+                d, sub = oracle.dist(vect, leg, quats[a])
+                if h2 > F(st.convex_radius) * F(st.convex_radius):
+                    cross = in_box(d, h)
+                else:
+                    dd = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(F) + d[:, 2] * d[:, 2]).astype(F)
+                    cross = dd < F(h2 + margin)
+                cross_count += cross
+                reach_count += sub.astype(int)
+            edge = cross_count > st.leg_count - st.leg_number_for_stab
+            reach = (reach_count >= st.leg_number_for_stab) | bool(parent_valid)
+            reach_any |= bool(reach.any())
+            leaf_any |= bool((reach & ~edge).any())
+            edge_any |= bool(edge.any())
+    return reach_any, leaf_any, edge_any
+
+
+def apply_oct(oracle, footholds, dim, st):
+    footholds = np.ascontiguousarray(footholds, F).reshape(-1, 3)
+    n_angles_max = st.angle_sample[0] * st.angle_sample[1] * st.angle_sample[2]
+    quats = [quat_from_angle_index(oracle, a, st) for a in range(n_angles_max)]
+    legs = octree_legs(dim, st)
     reach_len = F(F(F(dim[1] + dim[3]) + dim[5]) + dim[4])
     nodes = [dict(c=np.array(list(st.box_center), F), h=np.array(list(st.box_size), F), validity=False, leaf=False,
                   raw=True, on_edge=False, dead=False, children=None)]
@@ -89,30 +125,8 @@ def apply_oct(oracle, footholds, dim, st):
             n = nodes[idx]
             if n["validity"]:
                 continue
-            vect = (footholds - n["c"]).astype(F)
-            keep = in_box(vect, (parent["h"] + reach_len).astype(F))
-            vect = vect[keep]
-            reach_any = leaf_any = edge_any = False
-            if len(vect):
-                margin = F(0) if rot else F(F(st.enable_rot_below) / F(3))
-                h2 = F(F(n["h"][0] * n["h"][0] + n["h"][1] * n["h"][1]) + n["h"][2] * n["h"][2])
-                for a in range(n_angles_max if rot else 1):
-                    reach_count = np.zeros(len(vect), int)
-                    cross_count = np.zeros(len(vect), int)
-                    for leg in legs:
-                        d, sub = oracle.dist(vect, leg, quats[a])
-                        if h2 > F(st.convex_radius) * F(st.convex_radius):
-                            cross = in_box(d, n["h"])
-                        else:
-                            dd = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(F) + d[:, 2] * d[:, 2]).astype(F)
-                            cross = dd < F(h2 + margin)
-                        cross_count += cross
-                        reach_count += sub.astype(int)
-                    edge = cross_count > st.leg_count - st.leg_number_for_stab
-                    reach = (reach_count >= st.leg_number_for_stab) | bool(parent["validity"])
-                    reach_any |= bool(reach.any())
-                    leaf_any |= bool((reach & ~edge).any())
-                    edge_any |= bool(edge.any())
+            reach_any, leaf_any, edge_any = child_flags(oracle, footholds, n["c"], n["h"], parent["h"], bool(parent["validity"]), rot,
+                                                        st, legs, quats, reach_len)
             if reach_any:
                 n["validity"] = True
             if leaf_any:

@@ -211,3 +211,91 @@ def test_apply_oct_random_settings_three_traversals_agree(lrm, seed):
     for name, r in results.items():
         assert np.array_equal(got.view(np.uint32), r.view(np.uint32)), (name, len(got), len(r))
     print(f"seed {seed}: {n} footholds, half {half}, depth {st.max_depth}, {st.leg_count} legs, stability {st.leg_number_for_stab}: {len(got)} leaves")
+
+
+def test_config5_share_of_one_gpu_with_an_oracle_sample(lrm, oracle, mode):
+    """BASELINE config 5 at ONE GPU's share of the 1e8-point cloud: 1.25e7 footholds on a 10 m x 10 m relief, the
+    reference's settings (root box +-5000 mm, min box 100 mm, rotations below 50 mm), 4 legs, stability 3, depth 6.
+    The whole tree cannot be restated on the CPU (2e4 children x 1e5-1e7 footholds x 4 legs), so: invariants of the whole
+    tree, and for a sample of the children of every level the three flag bits the kernel returned against
+    tests/octree_oracle.child_flags over exactly the footholds the reference itself would test for that child (its
+    elongated-box cull, several_leg_octree.cu:76-82).  Deep levels (<= 4e5 footholds in the box): the flags must be
+    EQUAL.  The first levels (millions of footholds in the box): the oracle runs on a random 2e5 of them, and because
+    every flag is an OR over footholds its flags must be a SUBSET of the kernel's."""
+    if mode == "strict":
+        pytest.skip("one arithmetic mode is enough at this size (the modes are bit-identical)")
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from octree_oracle import child_flags, octree_legs, quat_from_angle_index
+    n = 12_500_000
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(-5000, 5000, (n, 2)).astype(np.float32)
+    z = (400 * np.sin(xy[:, 0] / 900) * np.cos(xy[:, 1] / 700) + 60 * np.sin(xy[:, 0] / 130) + rng.normal(0, 5, n).astype(np.float32) - 200).astype(np.float32)
+    f = np.column_stack([xy, z]).astype(np.float32)
+    del xy, z
+    dim = lrm.get_M2_leg(0.0)
+    st = lrm.octree_default_settings()
+    st.max_depth = 6
+    st.leg_number_for_stab = 3
+    t = torch.from_numpy(np.ascontiguousarray(f.T)).cuda()
+    lrm.dbg_oct_trace(True)
+    try:
+        leaves, ms = lrm.device.apply_oct(t[0], t[1], t[2], dim, st)
+        rec = lrm.dbg_oct_trace_read()
+    finally:
+        lrm.dbg_oct_trace(False)
+    leaves2, _ = lrm.device.apply_oct(t[0], t[1], t[2], dim, st)
+    del t
+    # ---- the whole tree ----
+    assert np.array_equal(leaves.view(np.uint32), leaves2.view(np.uint32)), "two runs, two trees"
+    depth = rec[:, 11].astype(int)
+    sizes = [int((depth == d).sum()) for d in range(6)]
+    assert sizes[0] == 8 and all(s % 8 == 0 and s > 0 for s in sizes), sizes
+    assert len(rec) > 15_000 and len(leaves) > 3_000
+    assert (np.abs(leaves) <= 5000).all()
+    flags = rec[:, 9].astype(int)
+    meta = rec[:, 10].astype(int)
+    assert not ((meta & 2) != 0).any()  # rotations only below 50 mm boxes: never at 78 mm
+    # a child is refined only when it is on an edge: every level's size is 8 x the on-edge (and not leaf) children of the one before
+    for d in range(5):
+        lv = depth == d
+        on_edge = ((flags[lv] & 4) != 0) & ((flags[lv] & 2) == 0) & ((meta[lv] & 4) == 0)
+        assert sizes[d + 1] == 8 * int(on_edge.sum()), (d, sizes)
+    # ---- a sample of children of every level against the oracle ----
+    order = np.argsort(f[:, 0], kind="stable")
+    fs = f[order]
+    del f, order
+    legs = octree_legs(dim, st)
+    quats = [quat_from_angle_index(oracle, a, st) for a in range(27)]
+    reach_len = np.float32(np.float32(np.float32(dim[1] + dim[3]) + dim[5]) + dim[4])
+    pick = np.random.default_rng(11)
+
+    def check(k):
+        c, h, ph = rec[k, 0:3], rec[k, 3:6], rec[k, 6:9]
+        ext = ph + reach_len
+        a, b = np.searchsorted(fs[:, 0], [c[0] - ext[0] - 1, c[0] + ext[0] + 1])
+        near = fs[a:b]
+        near = near[(np.abs(near[:, 1] - c[1]) <= ext[1] + 1) & (np.abs(near[:, 2] - c[2]) <= ext[2] + 1)]
+        exact = len(near) <= 400_000
+        if not exact:
+            near = near[np.random.default_rng(k).choice(len(near), 200_000, replace=False)]
+        want = child_flags(oracle, near, c, h, ph, bool(meta[k] & 1), bool(meta[k] & 2), st, legs, quats, reach_len)
+        want_bits = int(want[0]) | (int(want[1]) << 1) | (int(want[2]) << 2)
+        return k, exact, want_bits
+
+    todo = []
+    for d in range(6):
+        cand = np.flatnonzero((depth == d) & ((meta & 4) == 0))
+        todo += list(pick.choice(cand, min(16, len(cand)), replace=False))
+    with ThreadPoolExecutor(16) as ex:
+        res = list(ex.map(check, todo))
+    n_exact = 0
+    for k, exact, want_bits in res:
+        if exact:
+            n_exact += 1
+            assert flags[k] == want_bits, (k, depth[k], flags[k], want_bits)
+        else:
+            assert (want_bits & ~flags[k]) == 0, (k, depth[k], flags[k], want_bits)
+    assert n_exact >= 30
+    print(f"config-5 share: {n} footholds, depth 6: {len(rec)} children in levels of {sizes}, {len(leaves)} valid leaves, {ms:.0f} ms of kernels; "
+          f"{n_exact} sampled children equal to the oracle, {len(res) - n_exact} (first levels) consistent with a foothold sample")

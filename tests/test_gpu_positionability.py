@@ -243,3 +243,87 @@ def test_any_in_shape_with_tile_box_skipping(lrm, torch_cuda):
             want = _any_in_cylinder(centres, cloud, r, pz, mz)
             assert np.array_equal(c.cpu().numpy().astype(bool), want)
             assert 0 < want.mean() < 1
+
+
+# ---- device-resident sharded drivers (lrm_amd.shard with CUDA tensors; lrm_positionability_dev) ----------------------
+def _sharded_scene(lrm):
+    rng = np.random.default_rng(31)
+    bodies, targets = scene(900, 6000, seed=13)
+    targets[:, 2] = (8 * np.sin(targets[:, 0] / 300) + rng.normal(0, 1.5, len(targets))).astype(np.float32)
+    bodies[:, 2] = rng.uniform(-30, 700, len(bodies)).astype(np.float32)
+    legs = np.stack([lrm.get_M2_leg(k * np.pi / 2) for k in range(4)])
+    quats = np.asarray([(1, 0, 0, 0), (np.cos(np.pi / 16), 0, np.sin(np.pi / 16), 0), (np.cos(np.pi / 8), 0, 0, np.sin(np.pi / 8))], np.float32)
+    return bodies, targets, legs, quats
+
+
+def test_device_resident_positionability_equals_the_host_entry(lrm, torch_cuda):
+    """positionability_sharded on CUDA tensors (one process: culls, compactions and the sweep never leave the device)
+    == lrm_positionability on host arrays, with and without the reference's culls; lrm_positionability_dev's `active`
+    input is honoured."""
+    torch = torch_cuda
+    bodies, targets, legs, quats = _sharded_scene(lrm)
+    tb = torch.from_numpy(np.ascontiguousarray(bodies.T)).cuda()
+    tt = torch.from_numpy(np.ascontiguousarray(targets.T)).cuda()
+    for culls in (False, True):
+        want, _ = lrm.positionability(bodies, targets, legs, quats, reference_culls=culls)
+        got = lrm.shard.positionability_sharded(tb, tt, legs, quats, reference_culls=culls)
+        assert got.is_cuda and got.dtype == torch.uint8
+        assert np.array_equal(got.cpu().numpy(), want), culls
+        assert 0 < want.sum() < len(want)
+    active = torch.zeros(len(bodies), dtype=torch.uint8, device="cuda")
+    active[::2] = 1
+    acc, ms = lrm.device.positionability(tb[0].contiguous(), tb[1].contiguous(), tb[2].contiguous(), tt[0].contiguous(), tt[1].contiguous(),
+                                         tt[2].contiguous(), legs, quats, 0, active=active)
+    want, _ = lrm.positionability(bodies, targets, legs, quats, reference_culls=False)
+    want = want.copy()
+    want[1::2] = 0
+    assert ms > 0 and np.array_equal(acc.cpu().numpy(), want)
+    # any-flags with the cloud on the device
+    out, alll = lrm.shard.reach_any_target_sharded(tb, tt, legs, None)
+    ref, ref_all = lrm.device.reach_any(tb[0].contiguous(), tb[1].contiguous(), tb[2].contiguous(), tt[0].contiguous(), tt[1].contiguous(), tt[2].contiguous(), legs, None)
+    assert torch.equal(out, ref) and torch.equal(alll, ref_all)
+
+
+def _shard_dev_worker(rank, world, port, ret):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import lrm_amd
+    from test_gpu_positionability import _sharded_scene
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bodies, targets, legs, quats = _sharded_scene(lrm_amd)
+        tb = torch.from_numpy(np.ascontiguousarray(bodies.T)).cuda()
+        tt = torch.from_numpy(np.ascontiguousarray(targets.T)).cuda()
+        got = lrm_amd.shard.positionability_sharded(tb, tt, legs, quats, reference_culls=True)
+        # the cloud sharded instead: this rank's contiguous slice of the targets
+        lo, hi = lrm_amd.shard.shard_bounds(targets.shape[0], world, rank)
+        out, alll = lrm_amd.shard.reach_any_target_sharded(tb, tt[:, lo:hi].contiguous(), legs, None)
+        ret[rank] = (got.cpu().numpy().tobytes(), out.cpu().numpy().tobytes(), alll.cpu().numpy().tobytes())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_resident_sharded_drivers_over_two_ranks(lrm, torch_cuda):
+    """two ranks sharing this box's GPU (gloo: the exchanged bytes are staged through the host, everything else stays on the
+    device): the body-sharded sweep with culls and the target-sharded any-flags equal the single-process results"""
+    import os
+    import torch.multiprocessing as mp
+    torch = torch_cuda
+    bodies, targets, legs, quats = _sharded_scene(lrm)
+    want, _ = lrm.positionability(bodies, targets, legs, quats, reference_culls=True)
+    tb = torch.from_numpy(np.ascontiguousarray(bodies.T)).cuda()
+    tt = torch.from_numpy(np.ascontiguousarray(targets.T)).cuda()
+    ref, ref_all = lrm.device.reach_any(tb[0].contiguous(), tb[1].contiguous(), tb[2].contiguous(), tt[0].contiguous(), tt[1].contiguous(), tt[2].contiguous(), legs, None)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shard_dev_worker, args=(2, 31500 + os.getpid() % 1000, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert ret[r][0] == want.tobytes()
+        assert ret[r][1] == ref.cpu().numpy().tobytes() and ret[r][2] == ref_all.cpu().numpy().tobytes()

@@ -184,42 +184,40 @@ def test_tol_ineligible_leg_falls_back_to_bit_exact(lrm, oracle, torch_cuda):
     assert bits_equal(d.cpu().numpy().T, want_d).all()
 
 
-def test_tol_plane_table_variant_in_a_subprocess(lrm):
-    """LRM_TOL_PLANE_TABLE=1 (read once per process) routes clouds of >= 5e5 points through the plane-table kernel
-    (csrc/lrm_tolgrid.cpp + dist_tolgrid_kernel): same contract -- mask bit-exact, field inside the tolerance."""
-    import os
-    import subprocess
-    import sys
-    code = r"""
-import sys, numpy as np
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
-import torch, lrm_amd
-from conftest import random_cloud
-from tolcheck import TOL, field_error
-from oracle.orc import Oracle
-o = Oracle()
-lrm_amd.set_mode(lrm_amd.MODE_TOL)
-pts = random_cloud(1_000_003, seed=21)
-for leg, q in ((lrm_amd.get_M2_leg(0.0), (1, 0, 0, 0)), (lrm_amd.get_moonbot_leg(1.0), (0.98, 0.0, 0.15, 0.05))):
-    x, y, z = (torch.from_numpy(np.ascontiguousarray(pts[:, k])).cuda() for k in range(3))
-    n = len(pts)
-    bits = torch.empty((n + 63) // 64, dtype=torch.int64, device='cuda')
-    m, d, bits = lrm_amd.device.reach_dist(x, y, z, leg, q, mask=torch.empty(n, dtype=torch.uint8, device='cuda'), bits=bits)
-    torch.cuda.synchronize()
-    npts, nfull, nexact = lrm_amd.dbg_tol_queue_counts()
-    assert npts == n and 0 < nfull < 0.15 * n and nexact < 0.02 * n, (npts, nfull, nexact)
-    want_m = o.reach(pts, leg, q); want_d, _ = o.dist(pts, leg, q)
-    assert np.array_equal(m.cpu().numpy(), want_m)
-    packed = np.packbits(np.pad(want_m, (0, (-n) % 64)), bitorder='little').view(np.uint64)
-    assert np.array_equal(bits.cpu().numpy().view(np.uint64), packed)
-    e = field_error(pts, d.cpu().numpy().T, want_d, leg)
-    assert e['metric'].max() <= TOL, e['metric'].max()
-print('plane table ok')
-"""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LRM_TOL_PLANE_TABLE="1")
-    out = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "plane table ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+@pytest.mark.parametrize("table", ["0", "1", "2"])
+def test_tol_with_and_without_the_plane_table(lrm, oracle, torch_cuda, table, monkeypatch):
+    """LRM_TOL_TABLE (read per call): "0" the staged kernel, default the table kernel from 2e5 points on, "2" the table
+    kernel for every size.  Same contract either way -- mask and bit words bit-exact, field inside the tolerance -- on a
+    cloud above and one below the size threshold, and the queue statistics stay small."""
+    monkeypatch.setenv("LRM_TOL_TABLE", table)
+    for n, seed in ((1_000_003, 21), (60_001, 22)):
+        pts = random_cloud(n, seed=seed)
+        for leg, q in ((lrm.get_M2_leg(0.0), (1, 0, 0, 0)), (lrm.get_moonbot_leg(1.0), (0.98, 0.0, 0.15, 0.05))):
+            x, y, z = soa(torch_cuda, pts)
+            bits = torch_cuda.empty((n + 63) // 64, dtype=torch_cuda.int64, device="cuda")
+            m, d, bits = lrm.device.reach_dist(x, y, z, leg, q, mask=torch_cuda.empty(n, dtype=torch_cuda.uint8, device="cuda"), bits=bits)
+            torch_cuda.cuda.synchronize()
+            npts, nq, nover = lrm.dbg_tol_queue_counts()
+            assert npts == n and 0 < nq < 0.03 * n and nover == 0, (npts, nq, nover)
+            want_d, want_v = oracle.dist(pts, leg, q)
+            check_outputs(pts, m.cpu().numpy(), None, d.cpu().numpy().T, bits.cpu().numpy(), oracle.reach(pts, leg, q), want_v, want_d, leg)
+
+
+def test_tol_far_cloud_uses_the_outer_grid(lrm, oracle, torch_cuda):
+    """points beyond +-1024 mm of the femur joint (the inner grid's range) are answered by the outer grid, not by the
+    fix-up: the queue stays a few per cent and the results stay in tolerance"""
+    n = 500_000
+    pts = random_cloud(n, seed=33)
+    pts[:, 0] += 900.0
+    pts[::7, 1] *= 6.0  # some as far as 3 m out
+    leg = lrm.get_M2_leg(0.5)
+    x, y, z = soa(torch_cuda, pts)
+    m, d = lrm.device.reach_dist(x, y, z, leg, None)
+    torch_cuda.cuda.synchronize()
+    npts, nq, nover = lrm.dbg_tol_queue_counts()
+    assert npts == n and nq < 0.05 * n and nover == 0, (nq, nover)
+    want_d, want_v = oracle.dist(pts, leg)
+    check_outputs(pts, m.cpu().numpy(), None, d.cpu().numpy().T, None, oracle.reach(pts, leg), want_v, want_d, leg)
 
 
 def test_tol_random_legs_orientations_and_boundary_hugging_clouds():
