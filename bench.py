@@ -44,7 +44,7 @@ HI = np.array([700, 500, 300], np.float32)
 CHUNK = 1_000_000
 
 
-def committed_profile(points, mode):
+def committed_profile(points, mode, profiles_dir=None):
     """Figures that cannot be read inside the timed run (PMC counters need their own rocprofv3 passes): the latest
     committed profiles/r*_hbm_traffic.json / r*_valu.json recorded for this workload and mode -- used only when the
     kernel sources they were taken with (kernel_src_sha, lrm_amd/srchash.py) are the tree's; otherwise null + "stale"."""
@@ -52,7 +52,8 @@ def committed_profile(points, mode):
     from lrm_amd.srchash import kernel_src_sha
     sha = kernel_src_sha()
     out = {"traffic": None, "traffic_source": None, "valu_insts_per_eval": None, "valu_source": None, "kernel_src_sha": sha}
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+    profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
+    for path in sorted(glob.glob(os.path.join(profiles_dir, "r*_hbm_traffic.json")), reverse=True):
         try:
             rec = json.load(open(path))
         except (OSError, ValueError):
@@ -63,7 +64,7 @@ def committed_profile(points, mode):
             else:
                 out["traffic_source"] = f"stale: {os.path.basename(path)} was taken with other kernel sources"
             break
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(profiles_dir, "r*_valu.json")), reverse=True):
         try:
             rec = json.load(open(path))
         except (OSError, ValueError):
