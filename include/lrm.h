@@ -144,12 +144,22 @@ int lrm_dist_cpu(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, co
  * reference's RBDL model).  *ms = chrono milliseconds of the loop. */
 int lrm_rbdl_equiv_cpu(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, uint8_t* mask_out, double* ms);
 
-/* ---- device-resident entry points (no allocation, no copy, no sync) --------------------
+/* ---- device-resident entry points (launch only: no copy of the clouds, the caller synchronises) ----
  * Pointers are device pointers; coordinates are SoA (one f32 array per component: the same
  * layout the reference keeps on disk, several_leg.cpp:126-131).  `stream` is a hipStream_t
  * (NULL = default stream).  `n` need not be a multiple of anything; 16-byte aligned arrays
  * (hipMalloc / torch allocations are) take the vectorised kernels, anything else a scalar
- * variant with identical results.  Launch only: the caller synchronises. */
+ * variant with identical results.
+ * LRM_MODE_STRICT / LRM_MODE_FAST: nothing but the launch (no allocation, no host synchronisation).
+ * LRM_MODE_TOL (distance / fused calls): the first call for a (leg, orientation) compiles the mode's tables on the
+ * host (~0.3 ms; + ~30 ms once for the plane table of clouds of >= 2e5 points), uploads them, and allocates the doubt
+ * queues of this (device, stream); a later call with a larger n regrows the queues (hipFree + hipMalloc: a device-wide
+ * synchronisation).  lrm_tol_prepare does all of that ahead of time, after which the calls only launch -- graph
+ * capture and latency-critical loops call it first.  The table cache holds 64 (leg, orientation) pairs, least
+ * recently used out.  lrm_release_workspaces frees every cached device buffer (queues, tables, the host pipeline's
+ * buffers and streams, the multi-device communicators); the next call re-creates what it needs. */
+int lrm_tol_prepare(const LrmLegDimensions* leg, const float* quat, size_t n_max, void* stream);
+void lrm_release_workspaces(void);
 int lrm_reach_dev(const float* x, const float* y, const float* z, size_t n,
                   const LrmLegDimensions* leg, const float* quat, uint8_t* mask, void* stream);
 /* as lrm_reach_dev, plus a wave-ballot bit mask: bit (i & 63) of bits[i >> 6]
@@ -252,13 +262,25 @@ void lrm_octree_default_settings(LrmOctreeSettings* out);
 int lrm_apply_oct(const float* footholds_aos, size_t n, const LrmLegDimensions* dim,
                   const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out,
                   float* ms);
-/* The same tree on `world` GPUs, one process each (the reference is single-device): the children of every level are
- * dealt round-robin to the ranks and `exchange(flags, n, user)` must replace flags[0..n) by their element-wise MAXIMUM over
- * all ranks (e.g. an RCCL all-reduce; called once per level by every rank).  Every rank returns all valid leaves. */
-typedef void (*LrmOctExchange)(uint32_t* flags, size_t n, void* user);
+/* The same tree on several GPUs, one process each (the reference is single-device).  `exchange(flags, n, user)` must
+ * replace flags[0..n) by their element-wise BITWISE OR over all ranks and return 0 (non-zero: the call fails); it is
+ * called by every rank once with n = 1 before the first level and once per level.  A rank that fails locally still
+ * enters the exchange its peers wait in with 0xffffffff in every word, and a rank that reads 0xffffffff fails too.
+ * lrm_apply_oct_sharded: every rank holds all footholds, the children of a level are dealt round-robin to the ranks.
+ * lrm_apply_oct_partitioned(_dev): every rank holds ITS part of the footholds (any disjoint split of the cloud; a
+ *   spatial one keeps the work local) and evaluates every child against it -- a child's flags are ORs over
+ *   footholds, so the OR over the ranks is exact: BASELINE config 5 without a replica of the 1e8-point cloud per GPU.
+ * Every rank returns all valid leaves. */
+typedef int (*LrmOctExchange)(uint32_t* flags, size_t n, void* user);
 int lrm_apply_oct_sharded(const float* footholds_aos, size_t n, const LrmLegDimensions* dim,
                           const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out,
                           float* ms, int rank, int world, LrmOctExchange exchange, void* user);
+int lrm_apply_oct_partitioned(const float* local_footholds_aos, size_t n_local, const LrmLegDimensions* dim,
+                              const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out,
+                              float* ms, LrmOctExchange exchange, void* user);
+int lrm_apply_oct_partitioned_dev(const float* fx, const float* fy, const float* fz, size_t n_local, const LrmLegDimensions* dim,
+                                  const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out,
+                                  float* ms, LrmOctExchange exchange, void* user);
 /* The same with the footholds already on the device, one array per component (the layout of the other *_dev entry points;
  * the reference has no such call: apply_oct uploads its Array<float3> every time, several_leg_octree.cu:408-414).  The arrays
  * are read only (a sorted copy is made).  rank / world / exchange as lrm_apply_oct_sharded (0, 1, NULL, NULL on one GPU). */

@@ -85,6 +85,7 @@ def load():
         "lrm_dbg_toltab_host": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_shard_bounds": [sz, C.c_int, C.c_int, sz, vp, vp],
         "lrm_dbg_pair_counts": [vp],
+        "lrm_tol_prepare": [vp, vp, sz, vp],
         "lrm_positionability_dev": [vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, sz, C.c_int, vp, vp, vp],
         "lrm_dbg_oct_trace": [C.c_int],
         "lrm_dbg_oct_trace_read": [vp, sz, vp],
@@ -119,10 +120,16 @@ def load():
     L.lrm_apply_oct_sharded.restype = C.c_int
     L.lrm_apply_oct_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp, vp, C.c_int, C.c_int, vp, vp]
     L.lrm_apply_oct_dev.restype = C.c_int
+    L.lrm_apply_oct_partitioned.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp, vp, vp]
+    L.lrm_apply_oct_partitioned.restype = C.c_int
+    L.lrm_apply_oct_partitioned_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, vp]
+    L.lrm_apply_oct_partitioned_dev.restype = C.c_int
     L.lrm_rotate_leg_data.argtypes = [vp, vp, vp]
     L.lrm_rotate_leg_data.restype = None
     L.lrm_multi_release.argtypes = []
     L.lrm_multi_release.restype = None
+    L.lrm_release_workspaces.argtypes = []
+    L.lrm_release_workspaces.restype = None
     _lib = L
     return L
 
@@ -221,6 +228,15 @@ def apply_reach_dist(xyz, leg, quat=None):
     return m, d, ms.value
 
 
+def tol_prepare(leg, quat=None, n_max=0, stream=None):
+    """lrm_tol_prepare: LRM_MODE_TOL's tables and queues for (leg, orientation) and clouds of up to n_max points, ahead of time"""
+    check(load().lrm_tol_prepare(_ptr(_f32(leg, (14,))), _ptr(_quat(quat)), n_max, stream))
+
+
+def release_workspaces():
+    load().lrm_release_workspaces()
+
+
 def shard_bounds(n, world, rank, align=64):
     """lrm_shard_bounds: the C ABI's shard arithmetic (equal to lrm_amd.shard.shard_bounds)"""
     lo, hi = C.c_size_t(0), C.c_size_t(0)
@@ -314,56 +330,64 @@ def apply_oct(footholds, leg, settings=None, capacity=None):
         return out[: n_out.value].copy(), ms.value
 
 
-OCT_EXCHANGE = C.CFUNCTYPE(None, C.POINTER(C.c_uint32), C.c_size_t, C.c_void_p)
+OCT_EXCHANGE = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.c_void_p)
 
 
-def apply_oct_dev(x_ptr, y_ptr, z_ptr, n, leg, settings=None, rank=0, world=1, exchange=None, capacity=None):
-    """lrm_apply_oct_dev: the footholds as three device arrays (raw pointers) -> (centres float32[k,3], kernel ms)."""
+def _oct_call(fn, head_args, leg, settings, tail_args, exchange, capacity):
+    """One of the lrm_apply_oct* entry points with an optional exchange callback.  `exchange(flags: np.ndarray[uint32])`
+    must replace the array, in place, by its element-wise bitwise OR over all ranks.  An exception raised inside it is
+    kept, turned into a non-zero return (the library then fails the call instead of going on with flags that were never
+    combined) and re-raised here."""
     cap = capacity if capacity is not None else 65536  # valid leaves; a larger tree makes the call run twice
+    raised = []
 
     def _cb(ptr, m, _user):
-        exchange(np.ctypeslib.as_array(ptr, shape=(m,)))
+        try:
+            exchange(np.ctypeslib.as_array(ptr, shape=(m,)))
+            return 0
+        except BaseException as e:  # noqa: BLE001 -- must not propagate through the C frames
+            raised.append(e)
+            return 1
 
     cb = OCT_EXCHANGE(_cb) if exchange is not None else None
+    cb_arg = [C.cast(cb, C.c_void_p) if cb is not None else None, None]
     while True:
         out = np.zeros((max(cap, 1), 3), np.float32)
         n_out = C.c_size_t(0)
         ms = C.c_float(0)
-        rc = load().lrm_apply_oct_dev(x_ptr, y_ptr, z_ptr, n, _ptr(_f32(leg, (14,))),
-                                      None if settings is None else C.addressof(settings), _ptr(out), cap,
-                                      C.addressof(n_out), C.addressof(ms), rank, world,
-                                      C.cast(cb, C.c_void_p) if cb is not None else None, None)
-        if rc == -1 and n_out.value > cap and capacity is None:
-            cap = n_out.value
-            continue
-        if rc != 0:
-            raise LrmError(f"liblrm error {rc}: {load().lrm_octree_last_error().decode()}")
-        return out[: n_out.value].copy(), ms.value
-
-
-def apply_oct_sharded(footholds, leg, settings, rank, world, exchange, capacity=None):
-    """lrm_apply_oct_sharded: `exchange(flags: np.ndarray[uint32])` must replace the array, in place, by its
-    element-wise maximum over all ranks -> (centres float32[k,3], kernel ms); GPU."""
-    footholds = _f32(footholds, (-1, 3))
-    cap = capacity if capacity is not None else 65536  # valid leaves; a larger tree makes the call run twice
-
-    def _cb(ptr, n, _user):
-        exchange(np.ctypeslib.as_array(ptr, shape=(n,)))
-
-    cb = OCT_EXCHANGE(_cb)
-    while True:
-        out = np.zeros((max(cap, 1), 3), np.float32)
-        n_out = C.c_size_t(0)
-        ms = C.c_float(0)
-        rc = load().lrm_apply_oct_sharded(_ptr(footholds), len(footholds), _ptr(_f32(leg, (14,))),
-                                          None if settings is None else C.addressof(settings), _ptr(out), cap,
-                                          C.addressof(n_out), C.addressof(ms), rank, world, C.cast(cb, C.c_void_p), None)
+        rc = fn(*head_args, _ptr(_f32(leg, (14,))), None if settings is None else C.addressof(settings), _ptr(out), cap,
+                C.addressof(n_out), C.addressof(ms), *tail_args, *(cb_arg if (exchange is not None or tail_args) else []))
+        if raised:
+            raise raised[0]
         if rc == -1 and n_out.value > cap and capacity is None:
             cap = n_out.value  # every rank sees the same count and retries together
             continue
         if rc != 0:
             raise LrmError(f"liblrm error {rc}: {load().lrm_octree_last_error().decode()}")
         return out[: n_out.value].copy(), ms.value
+
+
+def apply_oct_dev(x_ptr, y_ptr, z_ptr, n, leg, settings=None, rank=0, world=1, exchange=None, capacity=None):
+    """lrm_apply_oct_dev: the footholds as three device arrays (raw pointers) -> (centres float32[k,3], kernel ms)."""
+    return _oct_call(load().lrm_apply_oct_dev, (x_ptr, y_ptr, z_ptr, n), leg, settings, (rank, world), exchange, capacity)
+
+
+def apply_oct_sharded(footholds, leg, settings, rank, world, exchange, capacity=None):
+    """lrm_apply_oct_sharded (every rank holds all footholds, the children of a level are dealt round-robin)
+    -> (centres float32[k,3], kernel ms); GPU."""
+    footholds = _f32(footholds, (-1, 3))
+    return _oct_call(load().lrm_apply_oct_sharded, (_ptr(footholds), len(footholds)), leg, settings, (rank, world), exchange, capacity)
+
+
+def apply_oct_partitioned(local_footholds, leg, settings, exchange, capacity=None):
+    """lrm_apply_oct_partitioned (every rank holds ITS part of the footholds, host array (n, 3)) -> (centres, kernel ms)"""
+    f = _f32(local_footholds, (-1, 3))
+    return _oct_call(load().lrm_apply_oct_partitioned, (_ptr(f), len(f)), leg, settings, (), exchange, capacity)
+
+
+def apply_oct_partitioned_dev(x_ptr, y_ptr, z_ptr, n, leg, settings, exchange, capacity=None):
+    """lrm_apply_oct_partitioned_dev: this rank's part of the footholds as three device arrays (raw pointers)"""
+    return _oct_call(load().lrm_apply_oct_partitioned_dev, (x_ptr, y_ptr, z_ptr, n), leg, settings, (), exchange, capacity)
 
 
 def dbg_sqrt_check_dev():

@@ -1,6 +1,7 @@
 // lrm_capi.cpp -- the extern "C" boundary of liblrm.so (include/lrm.h).
 #include "../../include/lrm.h"
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -53,20 +54,28 @@ struct TolEntry {
     std::vector<uint8_t> tab;      // the plane table (lrm_build_tol_tab), built on first use
     int tab_state = 0;             // 0 not built yet, 1 built, -1 this leg has none (too many rows)
     std::map<int, uint8_t*> tab_dev;
+    uint64_t last_use = 0;
 };
+uint64_t g_tol_clock = 0;
 std::map<TolKey, TolEntry> g_tol_cache;
 TolEntry& tol_entry(const LrmLegDimensions& leg, const float* quat, const LrmCompiledLeg& L) {
     TolKey k;
     std::memcpy(k.v, &leg, 14 * sizeof(float));
     std::memcpy(k.v + 14, quat, 4 * sizeof(float));
     auto it = g_tol_cache.find(k);
-    if (it != g_tol_cache.end()) return it->second;
-    if (g_tol_cache.size() >= 64) { // a sweep over many orientations: start over (device copies are released)
-        for (auto& e : g_tol_cache)
-            for (auto& d : e.second.tab_dev) (void)hipFree(d.second);
-        g_tol_cache.clear();
+    if (it != g_tol_cache.end()) {
+        it->second.last_use = ++g_tol_clock;
+        return it->second;
+    }
+    if (g_tol_cache.size() >= 64) { // a sweep over many orientations: the least recently used pair goes (hipFree waits for the device)
+        auto old = g_tol_cache.begin();
+        for (auto jt = g_tol_cache.begin(); jt != g_tol_cache.end(); ++jt)
+            if (jt->second.last_use < old->second.last_use) old = jt;
+        for (auto& d : old->second.tab_dev) (void)hipFree(d.second);
+        g_tol_cache.erase(old);
     }
     TolEntry& e = g_tol_cache[k];
+    e.last_use = ++g_tol_clock;
     lrm_compile_tol(L, &e.tl);
     return e;
 }
@@ -204,30 +213,58 @@ struct Events {
 
 // ---- pipelined host boundary (opt-in: LRM_HOST_PIPELINE=1) ---------------------------------------------------------
 // apply_kernel (cross_compiled.cu:41-77) allocates, copies the whole input, runs the kernel, copies the whole output and
-// frees, one after the other; for 1e7 fused points that is 16 ms of which 0.1-0.3 ms are kernels (pageable copies at
-// ~22 GB/s, one direction at a time).  With the pipeline the same call keeps its device buffers and three streams per
-// device, cuts the cloud into chunks (LRM_HOST_PIPELINE_CHUNK points, default 2^20: 12 MB in, 13 MB out) and runs
-//     H2D of chunk c + 1  ||  kernels of chunk c  ||  D2H of chunk c - 1
-// -- the two copy directions use PCIe's two directions at once.  The copies are issued from two helper threads: a
-// copy from / to pageable user memory occupies its calling thread (the runtime stages it through its own pinned
-// buffers), so one thread per direction is what lets them overlap; the caller's thread launches the kernels.
+// frees, one after the other; for 1e7 fused points that is 16 ms of which 0.1-0.3 ms are kernels.  Where the time goes on
+// this box (tools/pcie_probe.cpp, profiles/r03_pcie_probe.txt): a copy from / to memory the runtime has seen before runs
+// at 56 GB/s, but the caller's output arrays are fresh (`new float3[n]`, bench.cpp:125-131): a copy INTO never-touched
+// pages runs at 10 GB/s (one page fault per 4 KB, taken by the single thread that stages the copy) -- 13 of the 16 ms.
+// With the pipeline the call keeps its device buffers, a few pinned staging slots and a handful of helper threads per
+// device, and cuts the cloud into chunks (LRM_HOST_PIPELINE_CHUNK points, default 2^19: 6 MB in, 6.5 MB out; 2^20: 5.8 ms instead of 4.7):
+//     kIn threads:   caller's input chunk -> pinned slot (memcpy) -> device (async DMA)
+//     caller thread: the kernels of a chunk as soon as its input has landed
+//     kOut threads:  device -> pinned slot (async DMA) -> caller's output arrays (memcpy: the page faults of the fresh
+//                    arrays are taken by several threads at once, and overlap the DMA of the other chunks)
 // Results are the same bytes as without the pipeline (same kernels on sub-ranges; the tolerance mode's fix-up is per
 // launch anyway).  Returned ms = the sum of the chunks' kernel times (HIP events on the compute stream).
+// Three streams in all (compute, H2D, D2H): ROCm maps streams onto a handful of hardware queues, and with one stream per
+// helper thread a copy ended up queued behind another stream's event wait -- 6 ms stalls in one run out of two.  The
+// helper threads of a direction share its stream and wait on their own events.
+constexpr int kPipeIn = 4, kPipeOut = 4;
 struct HostPipe {
-    hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+    hipStream_t s_k = nullptr, s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_slot_in[kPipeIn] = {}, ev_slot_out[kPipeOut] = {};
     void *d_in = nullptr, *d_mask = nullptr, *d_out = nullptr;
-    size_t cap = 0; // points the device buffers hold
+    size_t cap = 0;        // points the device buffers hold
+    size_t slot_chunk = 0; // points a pinned slot holds
+    void *pin_in[kPipeIn] = {}, *pin_out[kPipeOut] = {}, *pin_mask[kPipeOut] = {};
     std::vector<hipEvent_t> ev_in, ev_k0, ev_k1;
 };
 std::map<int, HostPipe> g_host_pipe; // per device ordinal; lives until lrm_release_workspaces()
 size_t host_pipeline_chunk() {
     const char* e = std::getenv("LRM_HOST_PIPELINE_CHUNK");
     const long v = e ? std::atol(e) : 0;
-    return v >= 4096 ? ((size_t)v + 63) & ~(size_t)63 : (size_t)1 << 20;
+    return v >= 4096 ? ((size_t)v + 63) & ~(size_t)63 : (size_t)1 << 19;
 }
 bool host_pipeline_enabled() {
     const char* e = std::getenv("LRM_HOST_PIPELINE");
     return e && e[0] == '1';
+}
+void host_pipe_free(HostPipe& P) {
+    for (void* p : {P.d_in, P.d_mask, P.d_out})
+        if (p) (void)hipFree(p);
+    for (int k = 0; k < kPipeIn; k++) {
+        if (P.pin_in[k]) (void)hipHostFree(P.pin_in[k]);
+        if (P.ev_slot_in[k]) (void)hipEventDestroy(P.ev_slot_in[k]);
+    }
+    for (int k = 0; k < kPipeOut; k++) {
+        if (P.pin_out[k]) (void)hipHostFree(P.pin_out[k]);
+        if (P.pin_mask[k]) (void)hipHostFree(P.pin_mask[k]);
+        if (P.ev_slot_out[k]) (void)hipEventDestroy(P.ev_slot_out[k]);
+    }
+    for (hipStream_t st : {P.s_k, P.s_in, P.s_out})
+        if (st) (void)hipStreamDestroy(st);
+    for (auto* v : {&P.ev_in, &P.ev_k0, &P.ev_k1})
+        for (hipEvent_t e : *v) (void)hipEventDestroy(e);
+    P = HostPipe{};
 }
 int host_apply_pipelined(int op, const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat,
                          uint8_t* mask_out, float* dxyz_out, float* ms, const LrmCompiledLeg& L) {
@@ -235,10 +272,31 @@ int host_apply_pipelined(int op, const float* xyz, size_t n, const LrmLegDimensi
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
     HostPipe& P = g_host_pipe[dev];
     const bool want_mask = (op != 1) || mask_out;
-    if (!P.s_in) {
-        HIP_TRY(hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking), "hipStreamCreate");
+    const size_t chunk = host_pipeline_chunk();
+    if (!P.s_k) {
         HIP_TRY(hipStreamCreateWithFlags(&P.s_k, hipStreamNonBlocking), "hipStreamCreate");
+        HIP_TRY(hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking), "hipStreamCreate");
         HIP_TRY(hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking), "hipStreamCreate");
+        for (int k = 0; k < kPipeIn; k++) HIP_TRY(hipEventCreateWithFlags(&P.ev_slot_in[k], hipEventDisableTiming), "hipEventCreate");
+        for (int k = 0; k < kPipeOut; k++) HIP_TRY(hipEventCreateWithFlags(&P.ev_slot_out[k], hipEventDisableTiming), "hipEventCreate");
+    }
+    if (chunk > P.slot_chunk) {
+        for (int k = 0; k < kPipeIn; k++) {
+            if (P.pin_in[k]) (void)hipHostFree(P.pin_in[k]);
+            P.pin_in[k] = nullptr;
+        }
+        for (int k = 0; k < kPipeOut; k++) {
+            if (P.pin_out[k]) (void)hipHostFree(P.pin_out[k]);
+            if (P.pin_mask[k]) (void)hipHostFree(P.pin_mask[k]);
+            P.pin_out[k] = P.pin_mask[k] = nullptr;
+        }
+        P.slot_chunk = 0;
+        for (int k = 0; k < kPipeIn; k++) HIP_TRY(hipHostMalloc(&P.pin_in[k], chunk * 3 * sizeof(float), hipHostMallocDefault), "hipHostMalloc staging");
+        for (int k = 0; k < kPipeOut; k++) {
+            HIP_TRY(hipHostMalloc(&P.pin_out[k], chunk * 3 * sizeof(float), hipHostMallocDefault), "hipHostMalloc staging");
+            HIP_TRY(hipHostMalloc(&P.pin_mask[k], chunk, hipHostMallocDefault), "hipHostMalloc staging");
+        }
+        P.slot_chunk = chunk;
     }
     if (n > P.cap) {
         for (void** p : {&P.d_in, &P.d_mask, &P.d_out}) {
@@ -251,7 +309,6 @@ int host_apply_pipelined(int op, const float* xyz, size_t n, const LrmLegDimensi
         HIP_TRY(hipMalloc(&P.d_out, n * 3 * sizeof(float)), "hipMalloc gpu_out.elements");
         P.cap = n;
     }
-    const size_t chunk = host_pipeline_chunk();
     const size_t nchunks = (n + chunk - 1) / chunk;
     while (P.ev_in.size() < nchunks) {
         hipEvent_t a = nullptr, b = nullptr, c = nullptr;
@@ -265,52 +322,84 @@ int host_apply_pipelined(int op, const float* xyz, size_t n, const LrmLegDimensi
     float* d_in = static_cast<float*>(P.d_in);
     uint8_t* d_mask = static_cast<uint8_t*>(P.d_mask);
     float* d_out = static_cast<float*>(P.d_out);
-    // hand-over between the three host threads: how many chunks have their "input landed" / "kernels queued" event recorded
-    std::mutex mu;
+    // hand-over between the host threads: in_ready[c] = chunk c's "input landed" event is recorded; k_issued = chunks whose
+    // kernels are queued (their "kernels done" event recorded)
+    std::mutex mu, mu_in, mu_out;
     std::condition_variable cv;
-    size_t in_issued = 0, k_issued = 0;
-    hipError_t err_in = hipSuccess, err_out = hipSuccess;
+    std::vector<char> in_ready(nchunks, 0);
+    size_t k_issued = 0;
+    hipError_t err_copy = hipSuccess;
     bool abort = false;
-    std::thread t_in([&] {
-        hipError_t e = hipSetDevice(dev);
-        for (size_t c = 0; c < nchunks && e == hipSuccess; c++) {
-            const size_t lo = c * chunk, cnt = std::min(chunk, n - lo);
-            e = hipMemcpyAsync(d_in + 3 * lo, xyz + 3 * lo, cnt * 3 * sizeof(float), hipMemcpyHostToDevice, P.s_in);
-            if (e == hipSuccess) e = hipEventRecord(P.ev_in[c], P.s_in);
-            std::lock_guard<std::mutex> g(mu);
-            if (e != hipSuccess) { err_in = e; abort = true; }
-            else in_issued = c + 1;
-            cv.notify_all();
-            if (abort) break;
-        }
-    });
-    std::thread t_out([&] {
-        hipError_t e = hipSetDevice(dev);
-        for (size_t c = 0; c < nchunks && e == hipSuccess; c++) {
-            {
-                std::unique_lock<std::mutex> g(mu);
-                cv.wait(g, [&] { return k_issued > c || abort; });
-                if (abort) break;
+    auto fail_copy = [&](hipError_t e) {
+        std::lock_guard<std::mutex> g(mu);
+        if (err_copy == hipSuccess) err_copy = e;
+        abort = true;
+        cv.notify_all();
+    };
+    const bool dbg = std::getenv("LRM_HOST_PIPELINE_DEBUG") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    std::vector<std::thread> helpers;
+    for (int k = 0; k < kPipeIn; k++)
+        helpers.emplace_back([&, k] {
+            hipError_t e = hipSetDevice(dev);
+            for (size_t c = (size_t)k; c < nchunks && e == hipSuccess; c += kPipeIn) {
+                { std::lock_guard<std::mutex> g(mu); if (abort) return; }
+                const size_t lo = c * chunk, cnt = std::min(chunk, n - lo);
+                const double t0 = since();
+                std::memcpy(P.pin_in[k], xyz + 3 * lo, cnt * 3 * sizeof(float));
+                const double t1 = since();
+                {   // one thread at a time queues on the shared stream: copy + its two events stay together
+                    std::lock_guard<std::mutex> q(mu_in);
+                    e = hipMemcpyAsync(d_in + 3 * lo, P.pin_in[k], cnt * 3 * sizeof(float), hipMemcpyHostToDevice, P.s_in);
+                    if (e == hipSuccess) e = hipEventRecord(P.ev_in[c], P.s_in);
+                    if (e == hipSuccess) e = hipEventRecord(P.ev_slot_in[k], P.s_in);
+                }
+                if (dbg) std::fprintf(stderr, "  in[%d] chunk %zu: memcpy %.2f-%.2f ms\n", k, c, t0, t1);
+                if (e == hipSuccess) {
+                    std::lock_guard<std::mutex> g(mu);
+                    in_ready[c] = 1;
+                    cv.notify_all();
+                }
+                if (e == hipSuccess) e = hipEventSynchronize(P.ev_slot_in[k]); // the slot is free again
             }
-            const size_t lo = c * chunk, cnt = std::min(chunk, n - lo);
-            e = hipStreamWaitEvent(P.s_out, P.ev_k1[c], 0);
-            if (e == hipSuccess && want_mask && mask_out) e = hipMemcpyAsync(mask_out + lo, d_mask + lo, cnt, hipMemcpyDeviceToHost, P.s_out);
-            if (e == hipSuccess && op != 0) e = hipMemcpyAsync(dxyz_out + 3 * lo, d_out + 3 * lo, cnt * 3 * sizeof(float), hipMemcpyDeviceToHost, P.s_out);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(P.s_out);
-        if (e != hipSuccess) {
-            std::lock_guard<std::mutex> g(mu);
-            err_out = e;
-            abort = true;
-            cv.notify_all();
-        }
-    });
+            if (e != hipSuccess) fail_copy(e);
+        });
+    for (int k = 0; k < kPipeOut; k++)
+        helpers.emplace_back([&, k] {
+            hipError_t e = hipSetDevice(dev);
+            for (size_t c = (size_t)k; c < nchunks && e == hipSuccess; c += kPipeOut) {
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&] { return k_issued > c || abort; });
+                    if (abort) return;
+                }
+                const size_t lo = c * chunk, cnt = std::min(chunk, n - lo);
+                const bool mask_here = want_mask && mask_out, field_here = op != 0;
+                {
+                    std::lock_guard<std::mutex> q(mu_out);
+                    e = hipStreamWaitEvent(P.s_out, P.ev_k1[c], 0);
+                    if (e == hipSuccess && mask_here) e = hipMemcpyAsync(P.pin_mask[k], d_mask + lo, cnt, hipMemcpyDeviceToHost, P.s_out);
+                    if (e == hipSuccess && field_here) e = hipMemcpyAsync(P.pin_out[k], d_out + 3 * lo, cnt * 3 * sizeof(float), hipMemcpyDeviceToHost, P.s_out);
+                    if (e == hipSuccess) e = hipEventRecord(P.ev_slot_out[k], P.s_out);
+                }
+                const double t0 = since();
+                if (e == hipSuccess) e = hipEventSynchronize(P.ev_slot_out[k]);
+                const double t1 = since();
+                if (e == hipSuccess) {
+                    if (mask_here) std::memcpy(mask_out + lo, P.pin_mask[k], cnt);
+                    if (field_here) std::memcpy(dxyz_out + 3 * lo, P.pin_out[k], cnt * 3 * sizeof(float));
+                }
+                if (dbg) std::fprintf(stderr, "  out[%d] chunk %zu: D2H wait %.2f-%.2f, memcpy to the caller's arrays until %.2f ms\n", k, c, t0, t1, since());
+            }
+            if (e != hipSuccess) fail_copy(e);
+        });
     int rc = LRM_OK;
     hipError_t err_k = hipSuccess;
     for (size_t c = 0; c < nchunks; c++) {
         {
             std::unique_lock<std::mutex> g(mu);
-            cv.wait(g, [&] { return in_issued > c || abort; });
+            cv.wait(g, [&] { return in_ready[c] || abort; });
             if (abort) break;
         }
         const size_t lo = c * chunk, cnt = std::min(chunk, n - lo);
@@ -327,12 +416,13 @@ int host_apply_pipelined(int op, const float* xyz, size_t n, const LrmLegDimensi
         cv.notify_all();
         if (abort) break;
     }
-    t_in.join();
-    t_out.join();
+    const double t_launched = since();
+    for (auto& t : helpers) t.join();
+    if (dbg) std::fprintf(stderr, "host pipeline: %zu chunks of %zu points; kernels queued after %.2f ms, helpers done after %.2f ms\n", nchunks, chunk, t_launched, since());
     if (rc != LRM_OK) return rc;
-    HIP_TRY(err_in, "hipMemcpy gpu_in.elements");
     HIP_TRY(err_k, "Kernel launch");
-    HIP_TRY(err_out, "hipMemcpy gpu_out.elements");
+    HIP_TRY(err_copy, "hipMemcpy (pipelined)");
+    HIP_TRY(hipStreamSynchronize(P.s_k), "hipStreamSynchronize");
     float total = 0.f;
     for (size_t c = 0; c < nchunks; c++) {
         float e = 0.f;
@@ -1293,6 +1383,50 @@ struct MultiState { // releases everything on every exit path
 } // namespace
 
 extern "C" {
+
+// LRM_MODE_TOL ahead of time: tables compiled and uploaded, queues of (current device, stream) sized for n_max points
+int lrm_tol_prepare(const LrmLegDimensions* leg, const float* quat, size_t n_max, void* stream) {
+    if (!leg) return fail(LRM_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LRM_ENODEV, "no HIP device");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    if (!L.fast_ok) return LRM_OK; // this leg runs the strict kernels in every mode: nothing to prepare
+    TolEntry& E = tol_entry(*leg, quat_or_default(quat), L);
+    if (!E.tl.tol_ok) return LRM_OK; // falls back to LRM_MODE_FAST
+    const uint8_t* tab = nullptr;
+    if (tol_tab_wanted(n_max)) {
+        const int rc = tol_tab_device(E, &tab);
+        if (rc != LRM_OK) return rc;
+    }
+    uint32_t* w = nullptr;
+    return tol_workspace(std::max(lrm_tol_tab_queue_words(n_max), lrm_tol_queue_words(n_max)), stream, &w);
+}
+
+void lrm_release_workspaces(void) {
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (auto& w : g_tol_ws) {
+        if (!w.second.p) continue;
+        (void)hipSetDevice(w.first.first);
+        (void)hipFree(w.second.p);
+    }
+    g_tol_ws.clear();
+    g_tol_last = TolLast{};
+    for (auto& e : g_tol_cache)
+        for (auto& d : e.second.tab_dev) {
+            (void)hipSetDevice(d.first);
+            (void)hipFree(d.second);
+        }
+    g_tol_cache.clear();
+    for (auto& hp : g_host_pipe) {
+        (void)hipSetDevice(hp.first);
+        host_pipe_free(hp.second);
+    }
+    g_host_pipe.clear();
+    multi_release();
+    if (have) (void)hipSetDevice(cur);
+}
 
 // shard r of n items over `world` owners: [lo, hi), boundaries multiples of `align` (64: no ballot word straddles two
 // owners); ceil(n / world) rounded up to `align` per owner, the last ones may be short or empty.  = shard.shard_bounds

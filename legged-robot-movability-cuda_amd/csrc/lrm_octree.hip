@@ -446,9 +446,28 @@ int lrm_apply_oct_dev(const float* fx, const float* fy, const float* fz, size_t 
     return apply_oct_impl(nullptr, fx, fy, fz, nf, dim, st_in, centers_out, capacity, n_out, ms, rank, world, exchange, user);
 }
 
-// The same tree on `world` GPUs (one process each): the children of every level are dealt round-robin to the ranks,
-// each rank evaluates its share, and `exchange` combines the flag words (element-wise maximum: every child has exactly
-// one owner, the others contribute 0).  Every rank builds the identical tree and returns all valid leaves.
+// Foothold-partitioned tree (config 5 at scale: no rank holds the whole cloud): every rank passes ITS part of the footholds
+// (any disjoint split; a spatial one keeps the work local) and evaluates every child against it; the three flags of a
+// child are ORs over footholds, so the OR of the ranks' flag words is exactly the flag word of the whole cloud.
+int lrm_apply_oct_partitioned(const float* footholds, size_t nf_local, const LrmLegDimensions* dim, const LrmOctreeSettings* st_in,
+                              float* centers_out, size_t capacity, size_t* n_out, float* ms, LrmOctExchange exchange, void* user) {
+    if ((nf_local && !footholds) || !exchange) { g_oct_err = "null argument"; return LRM_EINVAL; }
+    return apply_oct_impl(footholds, nullptr, nullptr, nullptr, nf_local, dim, st_in, centers_out, capacity, n_out, ms, 0, 1, exchange, user);
+}
+int lrm_apply_oct_partitioned_dev(const float* fx, const float* fy, const float* fz, size_t nf_local, const LrmLegDimensions* dim,
+                                  const LrmOctreeSettings* st_in, float* centers_out, size_t capacity, size_t* n_out, float* ms,
+                                  LrmOctExchange exchange, void* user) {
+    if ((nf_local && !(fx && fy && fz)) || !exchange) { g_oct_err = "null argument"; return LRM_EINVAL; }
+    return apply_oct_impl(nullptr, fx, fy, fz, nf_local, dim, st_in, centers_out, capacity, n_out, ms, 0, 1, exchange, user);
+}
+
+// The same tree on `world` GPUs (one process each).  rank / world: the children of every level are dealt round-robin to the
+// ranks and each rank evaluates its share against (its copy of) all footholds; world = 1 with an exchange: every rank
+// evaluates every child against its own part of the footholds (lrm_apply_oct_partitioned).  Either way `exchange` combines
+// the flag words with a bitwise OR, every rank builds the identical tree and returns all valid leaves.
+// Failure protocol: the ranks exchange once per level and once (one word) before the first level.  A rank that fails
+// locally still takes part in the exchange its peers are waiting in, with kOctPoison in every word, and a rank that
+// reads kOctPoison fails too: nobody is left waiting in a collective.
 static int apply_oct_impl(const float* footholds /* host AoS, or null */, const float* dev_x, const float* dev_y, const float* dev_z,
                           size_t nf, const LrmLegDimensions* dim, const LrmOctreeSettings* st_in,
                           float* centers_out, size_t capacity, size_t* n_out, float* ms, int rank, int world,
@@ -457,6 +476,14 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
     if (!dim || !n_out || (nf && !footholds && !(dev_x && dev_y && dev_z)) || (capacity && !centers_out)) return fail(LRM_EINVAL, "null argument");
     if (nf >= ((size_t)1 << 31)) return fail(LRM_EINVAL, "more than 2^31 - 1 footholds: shard the cloud");
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !exchange)) return fail(LRM_EINVAL, "bad rank / world / exchange");
+    constexpr uint32_t kOctPoison = 0xffffffffu;
+    size_t peers_expect = exchange ? 1 : 0; // words the peers' next exchange carries (0: none pending)
+    auto abort_peers = [&]() {              // called on a local failure: do not leave the peers waiting
+        if (!exchange || peers_expect == 0) return;
+        std::vector<uint32_t> poison(peers_expect, kOctPoison);
+        peers_expect = 0;
+        (void)exchange(poison.data(), poison.size(), user);
+    };
     LrmOctreeSettings st;
     if (st_in) st = *st_in;
     else lrm_octree_default_settings(&st);
@@ -470,6 +497,7 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
         hipError_t e_ = (expr);                                                \
         if (e_ != hipSuccess) {                                                \
             g_oct_err = std::string(where) + ": " + hipGetErrorString(e_);     \
+            abort_peers();                                                     \
             cleanup();                                                         \
             return (e_ == hipErrorOutOfMemory) ? LRM_ENOMEM : LRM_ENODEV;      \
         }                                                                      \
@@ -592,6 +620,15 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
     OCT_TRY(hipEventCreate(&ev_b), "hipEventCreate");
 
     if (dbg) { fprintf(stderr, "apply_oct: %zu legs compiled and uploaded in %.2f ms\n", legs.size(), ms_since(t_phase)); t_phase = now(); }
+    if (exchange) { // every rank got this far?
+        uint32_t ready = 0;
+        peers_expect = 0;
+        if (exchange(&ready, 1, user) != 0 || ready == kOctPoison) {
+            g_oct_err = ready == kOctPoison ? "a peer rank failed before the first level" : "the exchange callback failed";
+            cleanup();
+            return LRM_ENODEV;
+        }
+    }
     std::vector<Node> nodes(1);
     for (int i = 0; i < 3; i++) {
         nodes[0].c[i] = st.box_center[i];
@@ -640,6 +677,7 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
             nodes[pi].raw = false;
         }
         const size_t nc = level.size();
+        peers_expect = exchange ? nc : 0;
         if (nc > children_cap) {
             if (d_children) (void)hipFree(d_children);
             if (d_flags) (void)hipFree(d_flags);
@@ -699,7 +737,17 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
             total_ms += e;
         }
         if (dbg) { fprintf(stderr, "apply_oct: level %d, %zu children: %.2f ms (host + kernel)\n", depth, nc, ms_since(t_phase)); t_phase = now(); }
-        if (world > 1) exchange(flags.data(), nc, user);
+        if (exchange) {
+            peers_expect = 0;
+            bool poisoned = exchange(flags.data(), nc, user) != 0;
+            const bool cb_failed = poisoned;
+            for (size_t k = 0; k < nc && !poisoned; k++) poisoned = flags[k] == kOctPoison;
+            if (poisoned) {
+                g_oct_err = cb_failed ? "the exchange callback failed" : "a peer rank failed";
+                cleanup();
+                return LRM_ENODEV;
+            }
+        }
         if (g_oct_trace)
             for (size_t k = 0; k < nc; k++) {
                 const OctChild& oc = level[k];

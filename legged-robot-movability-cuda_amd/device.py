@@ -188,6 +188,16 @@ def any_in_cylinder(cx, cy, cz, tx, ty, tz, radius, plus_z, minus_z, out=None):
     return out
 
 
+def apply_oct_partitioned(x, y, z, leg, settings, exchange):
+    """apply_oct with THIS rank's part of the footholds on the device (lrm_apply_oct_partitioned_dev); `exchange` ORs the
+    flag words over the ranks.  -> (centres float32[k, 3] on the host, kernel milliseconds)"""
+    torch = _torch()
+    n = _check_f32(x, y, z) if x.numel() else 0
+    with torch.cuda.device(x.device):
+        torch.cuda.synchronize(x.device)  # the library works on the null stream
+        return _capi.apply_oct_partitioned_dev(_dp(x) if n else None, _dp(y) if n else None, _dp(z) if n else None, n, leg, settings, exchange)
+
+
 def apply_oct(x, y, z, leg, settings=None, rank=0, world=1, exchange=None):
     """apply_oct on footholds that already live on the device (three float32 tensors); the level loop synchronises the
     device, so this is not a stream-ordered call.  -> (centres float32[k, 3] on the host, kernel milliseconds)"""

@@ -335,9 +335,57 @@ def reach_any_target_sharded(bodies, local_targets, legs, quat=None, backend=Non
     return out, out.min(axis=0)
 
 
+def _or_exchange(dist, group):
+    """the octree's exchange callback: flags[:] = bitwise OR over the ranks of a uint32 array of 3-bit flag words (or of
+    0xffffffff: a rank that failed).  RCCL has no bitwise-OR reduction: the three bits and the failure marker travel as
+    four 0/1 bytes per word and are combined with MAX."""
+    import torch
+    dev = _comm_device(dist, group)
+
+    def exchange(flags):
+        f = torch.from_numpy(flags.astype(np.int64))
+        planes = torch.stack([(f >> 0) & 1, (f >> 1) & 1, (f >> 2) & 1, (f == 0xffffffff).to(torch.int64)]).to(torch.uint8).to(dev)
+        dist.all_reduce(planes, op=dist.ReduceOp.MAX, group=group)
+        p = planes.cpu().numpy().astype(np.uint32)
+        out = p[0] | (p[1] << 1) | (p[2] << 2)
+        out[p[3] != 0] = 0xffffffff
+        flags[:] = out
+
+    return exchange
+
+
+def octant_owner(footholds, box_center, world):
+    """A spatial split for apply_oct_partitioned: the rank that owns each foothold = (index of the root box's octant the
+    foothold lies in) mod world.  footholds: host array (n, 3) -> int array [n].  Any disjoint split is CORRECT (a
+    child's flags are ORs over footholds); this one keeps a rank's footholds, and so its work, in its own subtrees."""
+    f = np.asarray(footholds, np.float32).reshape(-1, 3)
+    c = np.asarray(box_center, np.float32).reshape(3)
+    octant = (f[:, 0] >= c[0]).astype(np.int64) | ((f[:, 1] >= c[1]).astype(np.int64) << 1) | ((f[:, 2] >= c[2]).astype(np.int64) << 2)
+    return octant % max(int(world), 1)
+
+
+def apply_oct_partitioned(local_footholds, leg, settings=None, group=None):
+    """apply_oct (lrm_apply_oct) of a cloud that NO rank holds as a whole (BASELINE config 5 at scale: 1e8 footholds are
+    1.2 GB -- a replica per GPU is what this avoids): every rank passes its own part of the footholds -- a host array
+    (n, 3) or three CUDA tensors (x, y, z) -- evaluates every child of every level against it, and the flag words are OR-ed
+    over the ranks once per level (exact: a child's three flags are ORs over footholds).  Every rank returns all valid
+    leaves.  -> (centres float32[k, 3], this rank's kernel milliseconds)"""
+    from . import _capi, device
+    dist, world, rank = _dist_info(group)
+    on_device = isinstance(local_footholds, (tuple, list)) and len(local_footholds) == 3 and all(hasattr(t, "is_cuda") and t.is_cuda for t in local_footholds)
+    if dist is None or world == 1:
+        if on_device:
+            return device.apply_oct(local_footholds[0], local_footholds[1], local_footholds[2], leg, settings)
+        return _capi.apply_oct(local_footholds, leg, settings)
+    exchange = _or_exchange(dist, group)
+    if on_device:
+        return device.apply_oct_partitioned(local_footholds[0], local_footholds[1], local_footholds[2], leg, settings, exchange)
+    return _capi.apply_oct_partitioned(local_footholds, leg, settings, exchange)
+
+
 def apply_oct_sharded(footholds, leg, settings=None, group=None):
     """apply_oct (lrm_apply_oct) with the children of every octree level dealt round-robin to the ranks: each rank
-    evaluates its share on its GPU, the per-child flag words are combined with all_reduce(MAX) once per level (every
+    evaluates its share on its GPU, the per-child flag words are OR-ed over the ranks once per level (every
     child has one owner, the others contribute 0), and every rank returns all valid leaves.  Each rank holds all
     footholds, as a host array (n, 3) or as three CUDA tensors (x, y, z).  -> (centres float32[k, 3], this rank's kernel milliseconds)"""
     import torch
@@ -348,12 +396,7 @@ def apply_oct_sharded(footholds, leg, settings=None, group=None):
         if on_device:
             return device.apply_oct(footholds[0], footholds[1], footholds[2], leg, settings)
         return _capi.apply_oct(footholds, leg, settings)
-    dev = _comm_device(dist, group)
-
-    def exchange(flags):  # numpy view of the library's buffer: reduce in place
-        t = torch.from_numpy(flags.astype(np.int32)).to(dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        flags[:] = t.cpu().numpy().astype(np.uint32)
+    exchange = _or_exchange(dist, group)
 
     if on_device:  # (x, y, z) CUDA tensors: no host copy of the cloud
         return device.apply_oct(footholds[0], footholds[1], footholds[2], leg, settings, rank, world, exchange)

@@ -150,14 +150,22 @@ def _oct_worker(rank, world, port, ret):
         t = torch.from_numpy(np.ascontiguousarray(f.T)).cuda()
         dev, _ = lrm_amd.shard.apply_oct_sharded((t[0], t[1], t[2]), dim, st)
         assert got.tobytes() == dev.tobytes()
+        # foothold-partitioned: no rank holds the whole cloud.  A spatial split (the root box's octants) and an arbitrary
+        # one (every world-th foothold) must give the same tree: the flags are ORs over footholds.
+        own = lrm_amd.shard.octant_owner(f, st.box_center, world)
+        part, _ = lrm_amd.shard.apply_oct_partitioned(f[own == rank], dim, st)
+        mine = torch.from_numpy(np.ascontiguousarray(f[rank::world].T)).cuda()
+        part_dev, _ = lrm_amd.shard.apply_oct_partitioned((mine[0], mine[1], mine[2]), dim, st)
+        assert got.tobytes() == part.tobytes() == part_dev.tobytes(), (len(got), len(part), len(part_dev))
         ret[rank] = got.tobytes()
     finally:
         dist.destroy_process_group()
 
 
 def test_apply_oct_sharded_over_two_ranks_equals_single_process(lrm):
-    """The level-sharded octree (lrm_apply_oct_sharded: children dealt round-robin, flags combined with all_reduce MAX
-    per level) with two ranks sharing this box's GPU over gloo: both ranks return the single-process leaves."""
+    """The level-sharded octree (lrm_apply_oct_sharded: children dealt round-robin) and the foothold-partitioned one
+    (lrm_apply_oct_partitioned: every rank holds a part of the cloud; octant split and an arbitrary split), flags OR-ed
+    over the ranks per level, with two ranks sharing this box's GPU over gloo: both ranks return the single-process leaves."""
     import os
     import torch.multiprocessing as mp
     lrm.set_mode(lrm.MODE_FAST)
@@ -170,6 +178,37 @@ def test_apply_oct_sharded_over_two_ranks_equals_single_process(lrm):
     ret = mgr.dict()
     mp.spawn(_oct_worker, args=(2, 30500 + os.getpid() % 1000, ret), nprocs=2, join=True)
     assert ret[0] == want.tobytes() and ret[1] == want.tobytes()
+
+
+def test_octree_exchange_failures_fail_the_call(lrm):
+    """an exception inside the exchange callback must fail the call and come back to the caller (a ctypes callback that
+    returned nothing used to swallow it: the library went on with flags that were never combined); a rank that reads
+    the failure marker of a peer fails too"""
+    from lrm_amd import _capi
+    f = footholds(500, seed=3)
+    dim = lrm.get_M2_leg(0.0)
+    st = settings(lrm, 400.0, 3, stab=3)
+    calls = []
+
+    def boom(flags):
+        calls.append(len(flags))
+        if len(calls) == 2:
+            raise RuntimeError("all_reduce failed")
+
+    with pytest.raises(RuntimeError, match="all_reduce failed"):
+        _capi.apply_oct_partitioned(f, dim, st, boom)
+    assert calls == [1, 8]  # the one-word handshake, then the first level: nothing after the failure
+
+    def poisoned(flags):  # a peer that failed contributes 0xffffffff to every word
+        if len(flags) > 1:
+            flags[:] = 0xffffffff
+
+    with pytest.raises(lrm.LrmError, match="peer rank failed"):
+        _capi.apply_oct_partitioned(f, dim, st, poisoned)
+    # an identity exchange (a single rank's OR) gives the plain tree
+    want, _ = lrm.apply_oct(f, dim, st)
+    got, _ = _capi.apply_oct_partitioned(f, dim, st, lambda flags: None)
+    assert got.tobytes() == want.tobytes()
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])

@@ -332,3 +332,38 @@ def test_tol_host_buffer_api_ragged_sizes(lrm, oracle, n):
     m2, d2, _ = lrm.apply_reach_dist(pts, leg, q)
     check_outputs(pts, v, v, d, None, want_v, want_v, want_d, leg)
     check_outputs(pts, m2, None, d2, None, oracle.reach(pts, leg, q), want_v, want_d, leg)
+
+
+def test_tol_prepare_makes_the_calls_launch_only(lrm, oracle, torch_cuda):
+    """lrm_tol_prepare builds the tables and the queues ahead of time: the calls that follow allocate nothing (the device's
+    free memory does not move) and, being launch-only, can be captured in a HIP graph and replayed; lrm_release_workspaces
+    gives the memory back and the next call still works."""
+    torch = torch_cuda
+    n = 700_000
+    pts = random_cloud(n, seed=77)
+    leg = lrm.get_M2_leg(1.3)
+    q = (0.99, 0.05, 0.1, -0.02)
+    x, y, z = soa(torch, pts)
+    mask = torch.empty(n, dtype=torch.uint8, device="cuda")
+    field = torch.empty((3, n), dtype=torch.float32, device="cuda")
+    bits = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    lrm.tol_prepare(leg, q, n, side.cuda_stream)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            lrm.device.reach_dist(x, y, z, leg, q, mask=mask, out=field, bits=bits)
+        mask.zero_()
+        field.zero_()
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)  # nothing but the graph's own bookkeeping
+    want_d, want_v = oracle.dist(pts, leg, q)
+    check_outputs(pts, mask.cpu().numpy(), None, field.cpu().numpy().T, bits.cpu().numpy(), oracle.reach(pts, leg, q), want_v, want_d, leg)
+    del g
+    lrm.release_workspaces()
+    m2, d2 = lrm.device.reach_dist(x, y, z, leg, q)
+    torch.cuda.synchronize()
+    assert torch.equal(m2, mask) and torch.equal(d2, field)
