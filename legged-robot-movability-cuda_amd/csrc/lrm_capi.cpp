@@ -160,7 +160,7 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
             int dev = 0;
             (void)hipGetDevice(&dev);
             const size_t words = tab ? lrm_tol_tab_queue_words(n) : lrm_tol_queue_words(n);
-            g_tol_last = TolLast{dev, w, words / (LRM_TOL_SEG_CAP_WORDS + 1), n}; // workspace = counts[blocks] | queue[blocks * cap]
+            g_tol_last = TolLast{dev, w, words / (4 * LRM_TOL_SEG_CAP_WORDS + 4), n}; // workspace = counts[blocks, padded to 4 * blocks words] | 16-byte records[blocks * cap]
             return LRM_OK;
         }
     }

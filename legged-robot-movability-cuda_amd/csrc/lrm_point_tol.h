@@ -265,6 +265,9 @@ LRM_HD LrmTolTabView lrm_toltab_view(const uint8_t* tab, const LrmTabRow* rows, 
 #if defined(__HIP_DEVICE_COMPILE__)
 LRM_HD uint32_t lrm_tt_cell(const uint16_t* cells, uint32_t i) {
     typedef const __attribute__((address_space(1))) char* GP;
+#if defined(LRM_TAB_EXP_ONE_LINE) // timing experiment (wrong results): every look-up reads the same cache line
+    asm volatile("v_and_b32 %0, 31, %0" : "+v"(i));
+#endif
     return *(const __attribute__((address_space(1))) uint16_t*)((GP)cells + (i << 1));
 }
 #else

@@ -114,83 +114,15 @@ struct TolLds {
 
 // kOp 1: distance + optional validity byte; kOp 2: reach mask (+ bit words) + distance.  In this mode the two
 // flags are the same function of the point wherever no decision is in doubt.
-template <int kOp>
-__global__ __launch_bounds__(kBlock, 7) void dist_tol_kernel(
-    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
-    const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
-    float* __restrict__ dy, float* __restrict__ dz, uint32_t* __restrict__ queue, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t s_qn;
-#if LRM_TOL_LEG_IN_LDS
-    // The whole per-leg block in LDS, scalars included: an instruction with an SGPR operand issues at half rate on
-    // gfx950, and ~45 of the per-point multiplies and FMAs take a leg constant; read through
-    // LDS (broadcast ds_read, a separate issue port) they are VGPR-only, full-rate instructions.
-    __shared__ LrmTolLeg s_leg;
-    {
-        const LrmTolLeg& K = lrm_kernarg<LrmTolLeg>(kTolLegArg);
-        const uint4* src = reinterpret_cast<const uint4*>(&K);
-        for (int i = threadIdx.x; i < (int)(sizeof(LrmTolLeg) / 16); i += kBlock) reinterpret_cast<uint4*>(&s_leg)[i] = src[i];
-        if (threadIdx.x == 0) s_qn = 0;
-        __syncthreads();
-    }
-    const LrmTolLeg* Lp = &s_leg;
-    const LrmTolTables T{&s_leg.circ[0][0], &s_leg.feat[0]};
-#else
-    __shared__ TolLds s_tab;
-    const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
-    {
-        const float* csrc = reinterpret_cast<const float*>(&L.circ[0][0]);
-        const float* fsrc = reinterpret_cast<const float*>(&L.feat[0]);
-        for (int i = threadIdx.x; i < (int)(sizeof(s_tab.circ) / 4); i += kBlock) reinterpret_cast<float*>(s_tab.circ)[i] = csrc[i];
-        if (threadIdx.x < (int)(sizeof(s_tab.feat) / 4)) reinterpret_cast<float*>(s_tab.feat)[threadIdx.x] = fsrc[threadIdx.x];
-        if (threadIdx.x == 0) s_qn = 0;
-        __syncthreads();
-    }
-    const LrmTolTables T{s_tab.circ, s_tab.feat};
-#endif
-    // 32-bit point indices (the launch function guarantees n + grid stride < 2^32): array addressing is then a
-    // scalar base + a 32-bit VGPR offset instead of a 64-bit v_lshl_add_u64 per access (half-rate)
-    const uint32_t stride = gridDim.x * kBlock;
-    const uint32_t n_pad = (uint32_t)((n + 63) & ~(size_t)63); // whole waves iterate together (ballots below)
-    uint32_t* seg = queue + (size_t)blockIdx.x * kSegCap;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
-        bool m = false;
-        uint32_t doubt = 0;
-        if (i < n) {
-            LrmVec3 p{x[i], y[i], z[i]};
-#if LRM_TOL_LEG_IN_LDS
-            const LrmTolLeg* Lq = Lp;
-            asm volatile("" : "+v"(Lq)); // opaque per point: the constants are re-read where they are used, not held in ~40 VGPRs
-            m = lrm_dist_tol(*Lq, T, p, doubt);
-#else
-            m = lrm_dist_tol(L, T, p, doubt);
-#endif
-            doubt &= 0xffffu; // the statistics bits do not queue a point
-            dx[i] = p.x;
-            dy[i] = p.y;
-            dz[i] = p.z;
-            if (mask) mask[i] = m;
-        }
-        if (bits) {
-            const uint64_t w = __ballot(m);
-            if ((threadIdx.x & 63) == 0) bits[i >> 6] = w;
-        }
-#if !defined(LRM_TOL_NOQUEUE)
-        const uint64_t dm = __ballot(doubt != 0);
-        if (dm) { // rare (a quarter of the waves): one LDS atomic per wave with a doubtful lane
-            const int lane = threadIdx.x & 63;
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_qn, (uint32_t)__popcll(dm));
-            base = __shfl(base, 0);
-            if (doubt) {
-                const uint32_t slot = base + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
-                if (slot < (uint32_t)kSegCap) seg[slot] = (uint32_t)i; // beyond: the count tells the fix-up to redo the workgroup
-            }
-        }
-#endif
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
-}
+
+// A queued point travels as a 16-byte record {index, x, y, z}: the fix-up then reads its coordinates with the queue
+// (one or two lines per segment) instead of three scattered 4-byte loads per point (384 B of HBM traffic each), and has
+// one dependent memory round trip less.
+struct QueueRec {
+    uint32_t i;
+    float x, y, z;
+};
+static_assert(sizeof(QueueRec) == 16, "one 16-byte store / load per queued point");
 
 // ------------------------------------------------------------------------------------------------------------
 // Staged variant (LRM_TOL_STAGED): every lane evaluates the more promising yaw candidate of its point; the lanes
@@ -204,7 +136,7 @@ template <int kOp, bool kAoS = false>
 __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
-    float* __restrict__ dy, float* __restrict__ dz, uint32_t* __restrict__ queue, uint32_t* __restrict__ counts) {
+    float* __restrict__ dy, float* __restrict__ dz, QueueRec* __restrict__ queue, uint32_t* __restrict__ counts) {
     __shared__ TolLds s_tab;
     __shared__ uint32_t s_qn;
     __shared__ uint32_t s_cnt[2];
@@ -234,7 +166,7 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
     const LrmTolTables T{s_tab.circ, s_tab.feat};
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t n_pad = (uint32_t)((n + kBlock - 1) / kBlock) * kBlock; // whole workgroups iterate together (barriers below)
-    uint32_t* seg = queue + (size_t)blockIdx.x * kSegCap;
+    QueueRec* seg = queue + (size_t)blockIdx.x * kSegCap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t toff0 = threadIdx.x * 4u;
 #if defined(LRM_FIX_TRACE)
@@ -338,7 +270,11 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
             if (doubt) {
                 const uint32_t qs = qb + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
-                if (qs < (uint32_t)kSegCap) seg[qs] = i;
+                if (qs < (uint32_t)kSegCap) { // beyond: the count tells the fix-up to redo the workgroup.  The point comes back from the L2 (loaded a round ago)
+                    const LrmVec3 q = kAoS ? LrmVec3{lrm_at(x + 3 * rbase, 3u * toff), lrm_at(x + 3 * rbase, 3u * toff + 4u), lrm_at(x + 3 * rbase, 3u * toff + 8u)}
+                                           : LrmVec3{lrm_at(x + rbase, toff), lrm_at(y + rbase, toff), lrm_at(z + rbase, toff)};
+                    seg[qs] = QueueRec{i, q.x, q.y, q.z};
+                }
             }
         }
     }
@@ -372,7 +308,7 @@ template <int kOp, bool kAoS = false>
 __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
-    float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ tab, uint32_t* __restrict__ queue,
+    float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ tab, QueueRec* __restrict__ queue,
     uint32_t* __restrict__ counts) {
     __shared__ TabLds s_tab;
     __shared__ uint32_t s_qn;
@@ -394,9 +330,12 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
         __syncthreads();
     }
     const LrmTolTabView G = lrm_toltab_view(tab, s_tab.rows, s_tab.vrows);
+#if defined(LRM_FIX_TRACE)
+    if (threadIdx.x == 0 && blockIdx.x < 32768) g_main_trace[blockIdx.x * 2] = wall_clock64();
+#endif
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t n_pad = (uint32_t)((n + 63) & ~(size_t)63); // whole waves iterate together (ballots below)
-    uint32_t* seg = queue + (size_t)blockIdx.x * kSegCap;
+    QueueRec* seg = queue + (size_t)blockIdx.x * kSegCap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t toff0 = threadIdx.x * 4u;
     uint32_t round = 0;
@@ -438,12 +377,19 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
             if (doubt) {
                 const uint32_t qs = qb + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
-                if (qs < (uint32_t)kSegCap) seg[qs] = i;
+                if (qs < (uint32_t)kSegCap) { // beyond: the count tells the fix-up to redo the workgroup.  The point comes back from the L2 (loaded a round ago)
+                    const LrmVec3 q = kAoS ? LrmVec3{lrm_at(x + 3 * rbase, 3u * toff), lrm_at(x + 3 * rbase, 3u * toff + 4u), lrm_at(x + 3 * rbase, 3u * toff + 8u)}
+                                           : LrmVec3{lrm_at(x + rbase, toff), lrm_at(y + rbase, toff), lrm_at(z + rbase, toff)};
+                    seg[qs] = QueueRec{i, q.x, q.y, q.z};
+                }
             }
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
+#if defined(LRM_FIX_TRACE)
+    if (threadIdx.x == 0 && blockIdx.x < 32768) g_main_trace[blockIdx.x * 2 + 1] = wall_clock64();
+#endif
 }
 
 // Bit i of the ballot words an earlier launch wrote becomes `m`.  Only this lane ever changes that bit, so a plain
@@ -458,9 +404,6 @@ __device__ __forceinline__ void patch_bit(uint64_t* bits, size_t i, bool m) {
     else atomicAnd(w, ~bit);
 }
 
-#ifndef LRM_TOL_FIX_PAIR
-#define LRM_TOL_FIX_PAIR 1
-#endif
 // The fix-up launch is one latency chain per wave (tools/fix_trace.py: 2.4 us launch gap, 2.3 us tables / counts /
 // prefix, then ~1000 dependent instructions of the filtered code at one wave per SIMD, 6.6 us -- 14.7 us where a lane
 // needs the strict plane evaluation), and its waves are mostly empty (13 queued points on average).  So a point takes TWO
@@ -527,13 +470,13 @@ template <int kOp, bool kAoS = false>
 __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
-    float* __restrict__ dy, float* __restrict__ dz, const uint32_t* __restrict__ queue,
+    float* __restrict__ dy, float* __restrict__ dz, const QueueRec* __restrict__ queue,
     const uint32_t* __restrict__ counts, uint32_t nseg, uint32_t seg_cap, size_t main_stride) {
     __shared__ FixLds s_tab;
     __shared__ uint32_t s_pre[kSegPerWave + 1], s_cnt[kSegPerWave];
     constexpr uint32_t kQueueAhead = 16;
     static_assert(kSegPerWave * kQueueAhead <= kFixBlock, "one slot per thread");
-    __shared__ uint32_t s_q[kSegPerWave][kQueueAhead];
+    __shared__ QueueRec s_q[kSegPerWave][kQueueAhead];
     const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kFixLegArg);
     const uint32_t seg0 = blockIdx.x * kSegPerWave;
     const int lane = threadIdx.x;
@@ -554,7 +497,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     // counts instead of one round trip later; slots beyond a segment's count hold stale indices that are never used
     if (lane < kSegPerWave * kQueueAhead) {
         const uint32_t sj = (uint32_t)lane / kQueueAhead, so = (uint32_t)lane % kQueueAhead;
-        s_q[sj][so] = (seg0 + sj < nseg && so < seg_cap) ? queue[(size_t)(seg0 + sj) * seg_cap + so] : 0u;
+        s_q[sj][so] = (seg0 + sj < nseg && so < seg_cap) ? queue[(size_t)(seg0 + sj) * seg_cap + so] : QueueRec{0u, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     LRM_TRACE_FIX(1);
@@ -571,11 +514,9 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     if (any == 0) return; // nothing in doubt in these workgroups (wave-uniform)
     __syncthreads();
     const LrmDistTables T{s_tab.lists, s_tab.dist, s_tab.corners};
-#if LRM_TOL_FIX_PAIR
     constexpr int kPerPass = kFixBlock / 2; // points per pass of the wave
     const int slot = lane >> 1, cand = lane & 1;
-    auto redo = [&](size_t i) { // both lanes of the pair come here with the same i
-        LrmVec3 p = kAoS ? LrmVec3{x[3 * i], x[3 * i + 1], x[3 * i + 2]} : LrmVec3{x[i], y[i], z[i]};
+    auto redo = [&](size_t i, LrmVec3 p) { // both lanes of the pair come here with the same point
         const bool m = lrm_redo_pair<kOp>(L, T, p, cand);
         if (cand == 0) {
             if (kAoS) {
@@ -591,22 +532,6 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
             if (bits) patch_bit(bits, i, m);
         }
     };
-#else
-    constexpr int kPerPass = kFixBlock;
-    const int slot = lane;
-    auto redo = [&](size_t i) {
-        static_assert(!kAoS, "the one-lane-per-point fix-up is SoA only");
-        LrmVec3 p{x[i], y[i], z[i]};
-        bool m = false;
-        if (kOp == 2) lrm_reach_dist_global_filtered(L, T, p, m);
-        else m = lrm_dist_global_filtered(L, T, p);
-        dx[i] = p.x;
-        dy[i] = p.y;
-        dz[i] = p.z;
-        if (mask) mask[i] = m;
-        if (bits) patch_bit(bits, i, m);
-    };
-#endif
     const uint32_t total = s_pre[kSegPerWave];
     LRM_TRACE_FIX(2);
 #if defined(LRM_FIX_TRACE)
@@ -617,7 +542,8 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
 #pragma unroll
         for (int t = 1; t < kSegPerWave; t++) j += (s_pre[t] <= k) ? 1 : 0; // segments with nothing queued share a prefix
         const uint32_t off = k - s_pre[j];
-        redo((size_t)(off < kQueueAhead ? s_q[j][off] : queue[(size_t)(seg0 + j) * seg_cap + off]));
+        const QueueRec rec = off < kQueueAhead ? s_q[j][off] : queue[(size_t)(seg0 + j) * seg_cap + off];
+        redo((size_t)rec.i, LrmVec3{rec.x, rec.y, rec.z});
 #if defined(LRM_FIX_TRACE)
         if (lane == 0 && pass < 4 && blockIdx.x < 4096) g_fix_trace[blockIdx.x * 8 + 3 + pass] = wall_clock64();
         pass++;
@@ -627,11 +553,14 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     if (lane == 0 && blockIdx.x < 4096) g_fix_trace[blockIdx.x * 8 + 7] = total;
 #endif
     for (int j = 0; j < kSegPerWave; j++) {
-        if (s_cnt[j] <= seg_cap || main_stride == 0) continue; // wave-uniform (only dist_tol_kernel's fixed-size segments can overflow)
+        if (s_cnt[j] <= seg_cap || main_stride == 0) continue; // wave-uniform
         // every point of workgroup seg0 + j: i = (seg0 + j) * kBlock + t + round * main_stride
         for (size_t base = (size_t)(seg0 + j) * kBlock; base < n; base += main_stride)
             for (int t = slot; t < kBlock; t += kPerPass)
-                if (base + t < n) redo(base + t);
+                if (base + t < n) {
+                    const size_t i = base + t;
+                    redo(i, kAoS ? LrmVec3{x[3 * i], x[3 * i + 1], x[3 * i + 2]} : LrmVec3{x[i], y[i], z[i]});
+                }
     }
 }
 
@@ -649,7 +578,7 @@ static size_t tol_main_blocks(size_t n) {
     if (blocks == 0) blocks = 1;
     return blocks;
 }
-size_t lrm_tol_queue_words(size_t n) { return tol_main_blocks(n) * (kSegCap + 1); }
+size_t lrm_tol_queue_words(size_t n) { return tol_main_blocks(n) * (4 * kSegCap + 4); } // counts (padded to 16 bytes per workgroup) | 16-byte records
 
 hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz,
@@ -657,14 +586,9 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
     const size_t blocks = tol_main_blocks(n);
     const size_t cap = blocks;
     uint32_t* counts = workspace;
-    uint32_t* queue = workspace + cap;
-#if LRM_TOL_STAGED
+    QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * cap); // 16-byte aligned behind the counts
     if (op == 2) hipLaunchKernelGGL(dist_tol_staged_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts);
     else hipLaunchKernelGGL(dist_tol_staged_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts);
-#else
-    if (op == 2) hipLaunchKernelGGL(dist_tol_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts);
-    else hipLaunchKernelGGL(dist_tol_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts);
-#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
@@ -683,13 +607,13 @@ static size_t tab_main_blocks(size_t n) {
     if (blocks == 0) blocks = 1;
     return blocks;
 }
-size_t lrm_tol_tab_queue_words(size_t n) { return tab_main_blocks(n) * (kSegCap + 1); }
+size_t lrm_tol_tab_queue_words(size_t n) { return tab_main_blocks(n) * (4 * kSegCap + 4); }
 hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                                float* dz, uint32_t* workspace /* lrm_tol_tab_queue_words(n) uint32 */, hipStream_t st) {
     const size_t blocks = tab_main_blocks(n);
     uint32_t* counts = workspace;
-    uint32_t* queue = workspace + blocks;
+    QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
     if (op == 2) hipLaunchKernelGGL(dist_tab_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts);
     else hipLaunchKernelGGL(dist_tab_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts);
     hipError_t e = hipGetLastError();
@@ -704,7 +628,7 @@ hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const Lrm
                                    uint8_t* mask, float* dxyz, uint32_t* workspace, hipStream_t st) {
     const size_t blocks = tab_main_blocks(n);
     uint32_t* counts = workspace;
-    uint32_t* queue = workspace + blocks;
+    QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
     if (op == 2) hipLaunchKernelGGL((dist_tab_kernel<2, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, tab_dev, queue, counts);
     else hipLaunchKernelGGL((dist_tab_kernel<1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, tab_dev, queue, counts);
     hipError_t e = hipGetLastError();
@@ -719,10 +643,9 @@ hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const Lrm
 // The same two launches on the float3 arrays of the apply_kernel boundary (cross_compiled.cu:33-79): no bit words.
 hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, uint8_t* mask,
                                    float* dxyz, uint32_t* workspace /* lrm_tol_queue_words(n) uint32 */, hipStream_t st) {
-#if LRM_TOL_STAGED && LRM_TOL_FIX_PAIR
     const size_t blocks = tol_main_blocks(n);
     uint32_t* counts = workspace;
-    uint32_t* queue = workspace + blocks;
+    QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
     if (op == 2) hipLaunchKernelGGL((dist_tol_staged_kernel<2, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts);
     else hipLaunchKernelGGL((dist_tol_staged_kernel<1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts);
     hipError_t e = hipGetLastError();
@@ -732,8 +655,4 @@ hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const Lrm
     if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
     else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
     return hipGetLastError();
-#else
-    (void)op; (void)xyz; (void)n; (void)L; (void)TL; (void)mask; (void)dxyz; (void)workspace; (void)st;
-    return hipErrorNotSupported;
-#endif
 }
