@@ -3,17 +3,21 @@
 // Two launches per call, no host synchronisation between them and NO global atomics (a first version appended
 // the doubtful points to one queue with one atomicAdd per wave: 42 000 same-address atomics per 1e7 points cost
 // 0.42 ms, five times the arithmetic):
-//   dist_tol_staged_kernel  every point: FP32-FMA / v_rsq_f32 evaluation (no trigonometry, no IEEE sqrt / div), reach
-//                     mask + ballot bit words + distance vector.  The more promising yaw candidate in the owning lane; the
-//                     second one only where a lower bound cannot exclude it, compacted over the workgroup through LDS.  A
-//                     point with any decision inside its error band is appended to the SEGMENT of its workgroup (kSegCap
-//                     slots per workgroup, slot numbers from an LDS counter); the workgroup stores its count at the end.
-//                     (dist_tol_kernel: the unstaged form, both candidates in the owning lane, -DLRM_TOL_STAGED=0.)
-//   tol_fixup_kernel  one wave per kSegPerWave segments: prefix sum of their counts, then the queued points
-//                     (a few 1e-3 of the cloud), 32 at a time -- two lanes per point, one yaw candidate each -- through
-//                     the bit-exact filtered code of LRM_MODE_FAST, overwriting their outputs.  A segment that overflowed
-//                     (a cloud hugging a decision boundary) has ALL the points of its workgroup re-evaluated: slow, never
-//                     wrong.  Counts are rewritten by every call: nothing to reset.
+//   dist_tab_kernel   (clouds of >= 2e5 points) every point: FP32-FMA / v_rsq_f32 evaluation (no trigonometry, no IEEE
+//                     sqrt / div) in which a yaw candidate's plane evaluation is one look-up in the plane table with
+//                     deferred decisions (lrm_toltab.cpp) plus the reduced evaluation of what the cell names; both
+//                     candidates in the owning lane, no barrier in the loop.  Reach mask + ballot bit words + distance
+//                     vector.  A point with any decision inside its error band, or with an unanswered cell, is appended
+//                     as a 16-byte record {index, x, y, z} to the SEGMENT of its workgroup (kSegCap slots, slot numbers
+//                     from an LDS counter); the workgroup stores its count at the end.
+//   dist_tol_staged_kernel  (smaller clouds, legs without a table) the same with the full plane evaluation: the more
+//                     promising yaw candidate in the owning lane, the second one only where a lower bound cannot
+//                     exclude it, compacted over the workgroup through LDS (two barriers per round).
+//   tol_fixup_kernel  one workgroup per kSegPerWave segments: prefix sum of their counts, then the queued points
+//                     (0.5 % of the cloud), two lanes per point, one yaw candidate each, through the bit-exact filtered
+//                     code of LRM_MODE_FAST, overwriting their outputs.  A segment that overflowed (a cloud hugging a
+//                     decision boundary) has ALL the points of its workgroup re-evaluated: slow, never wrong.  Counts are
+//                     rewritten by every call: nothing to reset.
 // Layout as lrm_kernels.hip: SoA coordinates, byte mask, ballot words, SoA distance field.  The per-leg block
 // (LrmTolLeg, 1.5 KB) travels by value in the kernarg segment; its per-lane tables are staged in LDS.
 #include <hip/hip_runtime.h>
