@@ -358,7 +358,21 @@ __global__ __launch_bounds__(kBlock, kFast ? LRM_DIST_MIN_WAVES : LRM_DIST_STRIC
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         bool m = false;
-        const bool v = eval_reach_dist<kOp, kFast>(L, &s_tab, p, m);
+        bool v;
+        if (kOp == 2 && kFast) { // as dist_soa_kernel: the rare strict re-evaluation of the mask re-loads its point (16 B per lane of scratch otherwise)
+            uint32_t stat = 0;
+            LrmDistByproduct by;
+            v = lrm_dist_global_fast(L, LrmDistTables{s_tab.lists, s_tab.dist, s_tab.corners}, p, stat, &by);
+            bool doubt;
+            m = lrm_reach_from_dist(L, by, doubt);
+            if (doubt) {
+                size_t ii = i;
+                asm volatile("" : "+v"(ii));
+                m = lrm_reach_global(L, s_tab.lists, LrmVec3{xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2]});
+            }
+        } else {
+            v = eval_reach_dist<kOp, kFast>(L, &s_tab, p, m);
+        }
         dxyz[3 * i] = p.x;
         dxyz[3 * i + 1] = p.y;
         dxyz[3 * i + 2] = p.z;

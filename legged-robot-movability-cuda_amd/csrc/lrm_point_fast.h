@@ -184,7 +184,51 @@ struct LrmDistTables {
     const LrmCircle* lists;                        // [16] strict circle lists
     const LrmCompiledLeg::DistCircle* dist;        // [16]
     const LrmCircle* corners;                      // [LRM_N_CORNERS]
+    uint32_t force_strict;                         // self-test (LRM_TOL_SELFTEST): every plane evaluation takes the strict path
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// lrm_plane_dist (one_leg.cu:91-145, :167-208) of ONE plane point, evaluated by the whole wave: (x, y) is wave-uniform, every
+// lane returns the same result, bit for bit what lrm_plane_dist gives.  The strict evaluation is one dependent chain of
+// ~30 IEEE square roots and divisions (4 clamps x 4 validations + the corner points); here lane l < 16 clamps onto circle
+// l / 4 and validates the clamp point against circle l % 4, lanes 16 .. 16 + n_corners - 1 take one corner point each, and
+// the reference's sequential "keep the earlier candidate unless a later one is strictly closer" is the minimum of |d| with
+// ties to the lowest candidate number -- candidates sit in the lanes in the reference's order.
+// ALL 64 lanes of the wave must call it together.
+__device__ __forceinline__ bool lrm_plane_dist_coop(const LrmCompiledLeg& L, const LrmCircle* lists, float& x, float& y, int lane) {
+    x -= L.coxa_length;
+    const LrmCircle* list = lists + lrm_region(L, x, y) * LRM_N_CIRCLES;
+    const bool is_circle = lane < 4 * LRM_N_CIRCLES;
+    const int ci = lane - 4 * LRM_N_CIRCLES, nco = L.n_corners;
+    const bool is_corner = ci >= 0 && ci < nco;
+    const int ck = is_corner ? ci : 0;
+    const LrmCircle cl = list[is_circle ? (lane >> 2) : 0];
+    const float ccx = is_circle ? cl.x : L.corner_x[ck], ccy = is_circle ? cl.y : L.corner_y[ck], ccr = is_circle ? cl.r : 0.f;
+    const bool att = is_circle ? (cl.attract != 0.f) : true;
+    float cx = x, cy = y, d;
+    bool valid;
+    lrm_clamp_on(ccx, ccy, ccr, att, cx, cy, d, valid);
+    const bool okj = lrm_circle_valid(list[lane & 3], cx, cy);
+    const unsigned long long okm = __ballot(okj), vm = __ballot(valid);
+    const bool clamp_ok = ((okm >> (lane & ~3)) & 15ull) == 15ull;
+    const bool overall = (vm & 0xffffull) == 0xffffull; // lrm_clamp_on's `valid` of the four circles (each held by four lanes)
+    const float ad = fabsf(d);
+    const bool cand = (is_circle ? clamp_ok : (is_corner && !overall)) && (999999999999999.9f > ad); // `fabsf(best_d) > fabsf(d)` against the initial best_d
+    float key = cand ? ad : __builtin_inff();
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) key = fminf(key, __shfl_xor(key, off)); // candidates live in lanes 0 .. 25
+    const unsigned long long eq = __ballot(cand && ad == key) & 0xffffffffull;
+    float bx = 0.f, by = 0.f;
+    if (eq) {
+        const int w = __builtin_ctzll(eq);
+        bx = lrm_u2f((uint32_t)__builtin_amdgcn_readlane((int)lrm_f2u(cx), w));
+        by = lrm_u2f((uint32_t)__builtin_amdgcn_readlane((int)lrm_f2u(cy), w));
+    }
+    x -= bx;
+    y -= by;
+    return overall;
+}
+#endif
 
 // eval_plane_circles<DIST> + multi_circle_clamp with filtered decisions.  (x, y) in/out as in
 // lrm_plane_dist.  Every test is a signed distance to its decision boundary (mm): decisions are
@@ -193,6 +237,10 @@ struct LrmDistTables {
 // bits) through a 3-deep sorting network.  A decision inside its band sends this ONE call to the
 // strict lrm_plane_dist; a near-tie between the two nearest boundaries is resolved by evaluating
 // just those two with the strict clamp.  `unc` is only a statistic here.
+// kCoop (device, the fix-up kernel of LRM_MODE_TOL): ALL 64 lanes of the wave call this together; a lane whose filter is in
+// doubt does not run the strict evaluation alone (4.7 us of one lane's time, the tail of that launch) -- the wave runs it
+// for the lane (lrm_plane_dist_coop), one request after the other.
+template <bool kCoop = false>
 LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, float& x, float& y, uint32_t& unc) {
     const float x_in = x, y_in = y;
     x -= L.coxa_length;
@@ -291,6 +339,28 @@ LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, 
     lu |= !(cv - av > tie) ? 32u : 0u;            // no candidate at all (inf - inf), or a three-way near-tie
     unc |= lu;
     unc |= !(macc > 2.0f * band) ? 512u : 0u;     // statistic + the fused reach mask below: `overall` has less than twice the margin
+    lu |= T.force_strict;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (kCoop) {
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        unsigned long long req = __ballot(lu != 0u);
+        bool mine = false, res = false;
+        float rx = 0.f, ry = 0.f;
+        while (req) { // wave-uniform
+            const int w = __builtin_ctzll(req);
+            req &= req - 1ull;
+            float qx = lrm_u2f((uint32_t)__builtin_amdgcn_readlane((int)lrm_f2u(x_in), w));
+            float qy = lrm_u2f((uint32_t)__builtin_amdgcn_readlane((int)lrm_f2u(y_in), w));
+            const bool ov = lrm_plane_dist_coop(L, T.lists, qx, qy, lane);
+            if (lane == w) { mine = true; res = ov; rx = qx; ry = qy; }
+        }
+        if (mine) {
+            x = rx;
+            y = ry;
+            return res;
+        }
+    } else
+#endif
     if (lu) { // strict evaluation of this call (rare: a few 1e-4 of the calls)
         x = x_in;
         y = y_in;
@@ -325,6 +395,7 @@ LRM_HD bool lrm_plane_dist_fast(const LrmCompiledLeg& L, const LrmDistTables T, 
 
 // finish_finding_closest<bool> (one_leg.cu:215-278); `angle` is the strict atan2f value, so
 // every comparison on it is the strict comparison.
+template <bool kCoop = false>
 LRM_HD bool lrm_finish_closest_fast(const LrmCompiledLeg& L, const LrmDistTables T, LrmVec3& p, float angle,
                                     uint32_t& unc) {
     const bool mega = (angle > L.mega_hi) || (angle < L.mega_lo);
@@ -339,7 +410,7 @@ LRM_HD bool lrm_finish_closest_fast(const LrmCompiledLeg& L, const LrmDistTables
     p.x = p.x * c - p.y * s;
     p.y = buffer + p.y * c;
     const LrmVec3 save = p;
-    const bool was_valid = lrm_plane_dist_fast(L, T, p.x, p.z, unc);
+    const bool was_valid = lrm_plane_dist_fast<kCoop>(L, T, p.x, p.z, unc);
     if (was_valid && !mega) {
         // Is the nearer yaw-limit half-plane closer than the in-plane boundary?  Filter first:
         // |save.x*sin(th) + save.y*cos(th)| against |p|, th = -(limit - sat).

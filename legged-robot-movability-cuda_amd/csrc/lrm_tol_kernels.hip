@@ -140,7 +140,7 @@ template <int kOp, bool kAoS = false>
 __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
-    float* __restrict__ dy, float* __restrict__ dz, QueueRec* __restrict__ queue, uint32_t* __restrict__ counts) {
+    float* __restrict__ dy, float* __restrict__ dz, QueueRec* __restrict__ queue, uint32_t* __restrict__ counts, uint32_t selftest) {
     __shared__ TolLds s_tab;
     __shared__ uint32_t s_qn;
     __shared__ uint32_t s_cnt[2];
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         }
         uint32_t doubt = lu;
         const bool m = lrm_tol_finish(L, S, A, need, B, p, doubt) && live;
-        doubt = live ? (doubt & 0xffffu) : 0u;
+        doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u; // selftest: every point goes to the fix-up
         if (live) {
             if (kAoS) {
                 lrm_at(dx + 3 * rbase, 3u * toff) = p.x;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ tab, QueueRec* __restrict__ queue,
-    uint32_t* __restrict__ counts) {
+    uint32_t* __restrict__ counts, uint32_t selftest) {
     __shared__ TabLds s_tab;
     __shared__ uint32_t s_qn;
     const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
         }
         uint32_t doubt = 0;
         const bool m = lrm_tab_point(L, G, p, doubt) && live;
-        doubt = live ? (doubt & 0xffffu) : 0u;
+        doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u; // selftest: every point goes to the fix-up
         if (live) {
             if (kAoS) {
                 lrm_at(dx + 3 * rbase, 3u * toff) = p.x;
@@ -437,7 +437,7 @@ __device__ __forceinline__ bool lrm_redo_pair(const LrmCompiledLeg& L, const Lrm
     const float ang = lrm_atan2f(mine.y, mine.x);
     const float ang_flip = (ang > 0) ? ang - LRM_PI_F : ang + LRM_PI_F;
     uint32_t u_mine = 0;
-    const bool r_mine = lrm_finish_closest_fast(LRM_FRESH(L), T, mine, cand ? ang_flip : ang, u_mine);
+    const bool r_mine = lrm_finish_closest_fast<true>(LRM_FRESH(L), T, mine, cand ? ang_flip : ang, u_mine); // whole wave: see lrm_plane_dist_coop
     const LrmVec3 other{lrm_pair_swap(mine.x), lrm_pair_swap(mine.y), lrm_pair_swap(mine.z)};
     const bool r_other = lrm_pair_swap(r_mine ? 1u : 0u) != 0u;
     const uint32_t u_other = lrm_pair_swap(u_mine);
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const QueueRec* __restrict__ queue,
-    const uint32_t* __restrict__ counts, uint32_t nseg, uint32_t seg_cap, size_t main_stride) {
+    const uint32_t* __restrict__ counts, uint32_t nseg, uint32_t seg_cap, size_t main_stride, uint32_t selftest) {
     __shared__ FixLds s_tab;
     __shared__ uint32_t s_pre[kSegPerWave + 1], s_cnt[kSegPerWave];
     constexpr uint32_t kQueueAhead = 16;
@@ -517,12 +517,14 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     for (int j = 0; j < kSegPerWave; j++) any |= s_cnt[j];
     if (any == 0) return; // nothing in doubt in these workgroups (wave-uniform)
     __syncthreads();
-    const LrmDistTables T{s_tab.lists, s_tab.dist, s_tab.corners};
+    const LrmDistTables T{s_tab.lists, s_tab.dist, s_tab.corners, (selftest & 2u) ? 1u : 0u};
     constexpr int kPerPass = kFixBlock / 2; // points per pass of the wave
     const int slot = lane >> 1, cand = lane & 1;
-    auto redo = [&](size_t i, LrmVec3 p) { // both lanes of the pair come here with the same point
+    // Every lane of the wave comes here in every pass (`live`: this pair has a point): the strict plane evaluations inside
+    // are run by the whole wave (lrm_plane_dist_coop).  Both lanes of a pair hold the same point.
+    auto redo = [&](size_t i, LrmVec3 p, bool live) {
         const bool m = lrm_redo_pair<kOp>(L, T, p, cand);
-        if (cand == 0) {
+        if (live && cand == 0) {
             if (kAoS) {
                 dx[3 * i] = p.x;
                 dx[3 * i + 1] = p.y;
@@ -541,13 +543,18 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
 #if defined(LRM_FIX_TRACE)
     int pass = 0;
 #endif
-    for (uint32_t k = slot; k < total; k += kPerPass) {
-        int j = 0;
+    for (uint32_t k0 = 0; k0 < total; k0 += kPerPass) { // workgroup-uniform trip count
+        const uint32_t k = k0 + (uint32_t)slot;
+        const bool live = k < total;
+        QueueRec rec{0u, 300.f, 0.f, -100.f}; // a lane without a point evaluates a harmless one
+        if (live) {
+            int j = 0;
 #pragma unroll
-        for (int t = 1; t < kSegPerWave; t++) j += (s_pre[t] <= k) ? 1 : 0; // segments with nothing queued share a prefix
-        const uint32_t off = k - s_pre[j];
-        const QueueRec rec = off < kQueueAhead ? s_q[j][off] : queue[(size_t)(seg0 + j) * seg_cap + off];
-        redo((size_t)rec.i, LrmVec3{rec.x, rec.y, rec.z});
+            for (int t = 1; t < kSegPerWave; t++) j += (s_pre[t] <= k) ? 1 : 0; // segments with nothing queued share a prefix
+            const uint32_t off = k - s_pre[j];
+            rec = off < kQueueAhead ? s_q[j][off] : queue[(size_t)(seg0 + j) * seg_cap + off];
+        }
+        redo((size_t)rec.i, LrmVec3{rec.x, rec.y, rec.z}, live);
 #if defined(LRM_FIX_TRACE)
         if (lane == 0 && pass < 4 && blockIdx.x < 4096) g_fix_trace[blockIdx.x * 8 + 3 + pass] = wall_clock64();
         pass++;
@@ -560,15 +567,25 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
         if (s_cnt[j] <= seg_cap || main_stride == 0) continue; // wave-uniform
         // every point of workgroup seg0 + j: i = (seg0 + j) * kBlock + t + round * main_stride
         for (size_t base = (size_t)(seg0 + j) * kBlock; base < n; base += main_stride)
-            for (int t = slot; t < kBlock; t += kPerPass)
-                if (base + t < n) {
-                    const size_t i = base + t;
-                    redo(i, kAoS ? LrmVec3{x[3 * i], x[3 * i + 1], x[3 * i + 2]} : LrmVec3{x[i], y[i], z[i]});
-                }
+            for (int t = slot; t < kBlock; t += kPerPass) { // kBlock / kPerPass passes for every lane
+                const size_t i = base + t;
+                const bool live = i < n;
+                LrmVec3 p{300.f, 0.f, -100.f};
+                if (live) p = kAoS ? LrmVec3{x[3 * i], x[3 * i + 1], x[3 * i + 2]} : LrmVec3{x[i], y[i], z[i]};
+                redo(i, p, live);
+            }
     }
 }
 
 } // namespace
+
+// LRM_TOL_SELFTEST (tests): bit 0 -- every point is queued (every workgroup's segment overflows: the fix-up re-evaluates the
+// whole cloud, so the outputs must be bit-identical to LRM_MODE_FAST); bit 1 -- every plane evaluation of the fix-up takes
+// the strict path, i.e. the wave-cooperative lrm_plane_dist_coop (still bit-identical).
+static uint32_t tol_selftest() {
+    const char* e = getenv("LRM_TOL_SELFTEST");
+    return e ? (uint32_t)atoi(e) & 3u : 0u;
+}
 
 // Workgroups of the main kernel for n points: every resident slot LRM_TOL_GRID_MULT times over, and for larger clouds as many
 // as keep a workgroup at about three rounds -- its doubt segment (kSegCap slots) is sized for that.  (With a fixed grid a
@@ -591,22 +608,25 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
     const size_t cap = blocks;
     uint32_t* counts = workspace;
     QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * cap); // 16-byte aligned behind the counts
-    if (op == 2) hipLaunchKernelGGL(dist_tol_staged_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts);
-    else hipLaunchKernelGGL(dist_tol_staged_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts);
+    if (op == 2) hipLaunchKernelGGL(dist_tol_staged_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts, tol_selftest());
+    else hipLaunchKernelGGL(dist_tol_staged_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts, tol_selftest());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
     const size_t stride = blocks * kBlock;
-    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
-    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
+    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
     return hipGetLastError();
 }
 
 // Table variant: tab_dev = the device copy of lrm_build_tol_tab's table for TL.  Same workspace layout and fix-up as above.
+#ifndef LRM_TAB_ROUNDS
+#define LRM_TAB_ROUNDS 3 // rounds of a workgroup on large clouds: its doubt segment (kSegCap slots) then holds 17 % of its points
+#endif
 static size_t tab_main_blocks(size_t n) {
     const size_t base = (size_t)256 * LRM_TAB_MIN_WAVES * LRM_TAB_GRID_MULT; // workgroups of four waves: every resident slot LRM_TAB_GRID_MULT times over
     const size_t need = (n + kBlock - 1) / kBlock;
-    size_t blocks = std::max(base, (need + 2) / 3);
+    size_t blocks = std::max(base, (need + LRM_TAB_ROUNDS - 1) / LRM_TAB_ROUNDS);
     if (blocks > need) blocks = need;
     if (blocks == 0) blocks = 1;
     return blocks;
@@ -618,14 +638,14 @@ hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const flo
     const size_t blocks = tab_main_blocks(n);
     uint32_t* counts = workspace;
     QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
-    if (op == 2) hipLaunchKernelGGL(dist_tab_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts);
-    else hipLaunchKernelGGL(dist_tab_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts);
+    if (op == 2) hipLaunchKernelGGL(dist_tab_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts, tol_selftest());
+    else hipLaunchKernelGGL(dist_tab_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts, tol_selftest());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
     const size_t stride = blocks * kBlock;
-    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
-    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
+    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
     return hipGetLastError();
 }
 hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const uint8_t* tab_dev,
@@ -633,14 +653,14 @@ hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const Lrm
     const size_t blocks = tab_main_blocks(n);
     uint32_t* counts = workspace;
     QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
-    if (op == 2) hipLaunchKernelGGL((dist_tab_kernel<2, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, tab_dev, queue, counts);
-    else hipLaunchKernelGGL((dist_tab_kernel<1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, tab_dev, queue, counts);
+    if (op == 2) hipLaunchKernelGGL((dist_tab_kernel<2, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, tab_dev, queue, counts, tol_selftest());
+    else hipLaunchKernelGGL((dist_tab_kernel<1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, tab_dev, queue, counts, tol_selftest());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
     const size_t stride = blocks * kBlock;
-    if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
-    else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
+    else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
     return hipGetLastError();
 }
 
@@ -650,13 +670,13 @@ hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const Lrm
     const size_t blocks = tol_main_blocks(n);
     uint32_t* counts = workspace;
     QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
-    if (op == 2) hipLaunchKernelGGL((dist_tol_staged_kernel<2, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts);
-    else hipLaunchKernelGGL((dist_tol_staged_kernel<1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts);
+    if (op == 2) hipLaunchKernelGGL((dist_tol_staged_kernel<2, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, tol_selftest());
+    else hipLaunchKernelGGL((dist_tol_staged_kernel<1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, tol_selftest());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
     const size_t stride = blocks * kBlock;
-    if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
-    else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride);
+    if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
+    else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
     return hipGetLastError();
 }

@@ -367,3 +367,37 @@ def test_tol_prepare_makes_the_calls_launch_only(lrm, oracle, torch_cuda):
     m2, d2 = lrm.device.reach_dist(x, y, z, leg, q)
     torch.cuda.synchronize()
     assert torch.equal(m2, mask) and torch.equal(d2, field)
+
+
+@pytest.mark.parametrize("selftest", ["1", "3"])
+def test_fixup_alone_is_bit_identical_to_the_bit_exact_mode(lrm, torch_cuda, selftest, monkeypatch):
+    """LRM_TOL_SELFTEST: bit 0 queues EVERY point (all segments overflow, so the fix-up launch re-evaluates the whole cloud
+    with the bit-exact code, two lanes per point); bit 1 also sends every plane evaluation of it through the strict path,
+    which the fix-up runs wave-cooperatively (lrm_plane_dist_coop: 16 lanes for the clamps and validations, the corner
+    points on their own lanes, an ordered minimum for the reference's "first strictly closer").  Either way every output
+    bit must equal LRM_MODE_FAST -- masks, bit words, all three floats of every vector, nan patterns included -- for the
+    SoA kernels and for the float3 ones of the apply_kernel boundary."""
+    torch = torch_cuda
+    pts = random_cloud(300_007, seed=123)
+    pts[::1001] = np.float32(np.nan)
+    pts[5::997, 0] = np.float32(181.0)  # on and around the coxa axis of the moonbot leg
+    pts[5::997, 1] = np.float32(0.0)
+    x, y, z = soa(torch, pts)
+    n = len(pts)
+    for leg, q in ((lrm.get_M2_leg(0.0), None), (lrm.get_moonbot_leg(2.1), (0.96, 0.1, -0.2, 0.15)), (lrm.get_M2_leg(-1.0), (0.924, 0, -0.384, 0))):
+        lrm.set_mode(lrm.MODE_FAST)
+        monkeypatch.delenv("LRM_TOL_SELFTEST", raising=False)
+        bits0 = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
+        m0, d0, bits0 = lrm.device.reach_dist(x, y, z, leg, q, mask=torch.empty(n, dtype=torch.uint8, device="cuda"), bits=bits0)
+        a0 = lrm.apply_reach_dist(pts[:70_001], leg, q)
+        lrm.set_mode(lrm.MODE_TOL)
+        monkeypatch.setenv("LRM_TOL_SELFTEST", selftest)
+        for table in ("0", "2"):
+            monkeypatch.setenv("LRM_TOL_TABLE", table)
+            bits1 = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
+            m1, d1, bits1 = lrm.device.reach_dist(x, y, z, leg, q, mask=torch.empty(n, dtype=torch.uint8, device="cuda"), bits=bits1)
+            torch.cuda.synchronize()
+            assert torch.equal(m0, m1) and torch.equal(bits0, bits1)
+            assert bits_equal(d0.cpu().numpy(), d1.cpu().numpy()).all(), (selftest, table)
+            a1 = lrm.apply_reach_dist(pts[:70_001], leg, q)
+            assert np.array_equal(a0[0], a1[0]) and bits_equal(a0[1], a1[1]).all()
