@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -23,7 +24,8 @@
 namespace {
 
 thread_local std::string g_err;
-int g_mode = LRM_MODE_FAST; // bit-identical to LRM_MODE_STRICT (tests/test_gpu_parity.py runs both)
+// Process-wide, as documented in lrm.h; atomic so that a helper thread (the host pipeline's) or a second caller thread reads a whole value.
+std::atomic<int> g_mode{LRM_MODE_FAST}; // bit-identical to LRM_MODE_STRICT (tests/test_gpu_parity.py runs both)
 const float kQuatTest[4] = {1.f, 0.f, 0.f, 0.f}; // settings.h:51
 
 int fail(int code, const char* what) {
