@@ -301,8 +301,14 @@ LRM_HD void lrm_toltab_lookup2(const uint16_t* cells, float inv, uint32_t cbase,
 // Same arithmetic as lrm_tol_plane on those operands.  x = abscissa - coxa_length.
 LRM_HD void lrm_tol_plane_tab(const LrmTolTabView& G, uint32_t code, float x, float z, float band, float tau,
                               float& du, float& dz, bool& valid, uint32_t& doubt) {
-    const LrmTabVRow vr = G.vrows[(code >> 10) & 31u];
-    const LrmTabRow ra = G.rows[code & 31u], rb = G.rows[(code >> 5) & 31u];
+#if defined(LRM_TAB_EXP_ONE_ROW) && defined(__HIP_DEVICE_COMPILE__) // timing experiment (wrong results): every lane reads the same rows -- no LDS bank conflicts
+    uint32_t code_rows = code;
+    asm volatile("v_and_b32 %0, 0x421, %0" : "+v"(code_rows));
+#else
+    const uint32_t code_rows = code;
+#endif
+    const LrmTabVRow vr = G.vrows[(code_rows >> 10) & 31u];
+    const LrmTabRow ra = G.rows[code_rows & 31u], rb = G.rows[(code_rows >> 5) & 31u];
     float vacc;
     {
         const float vx = x - vr.x, vy = z - vr.y;
