@@ -166,6 +166,7 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
             return LRM_OK;
         }
     }
+    g_tol_last = TolLast{}; // this call ran the bit-exact kernels (mode, or a leg outside the tolerance mode's eligibility): no queue statistic
     HIP_TRY(lrm_launch_dist_soa(op, x, y, z, n, L, mask, bits, dx, dy, dz, g_mode != LRM_MODE_STRICT, (hipStream_t)stream),
             "distance launch");
     return LRM_OK;

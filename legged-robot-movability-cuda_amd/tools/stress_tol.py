@@ -34,7 +34,9 @@ def main():
     n = args.points
     tol = 1e-5
     out = {"legs": 0, "tol_eligible": 0, "cases": 0, "evaluations": 0, "mask_mismatches": 0, "bit_word_mismatches": 0,
-           "nonfinite": 0, "max_err": 0.0, "worst": None}
+           "nonfinite": 0, "max_err": 0.0, "worst": None, "max_queued_fraction": 0.0, "mean_queued_fraction": 0.0,
+           "overflowed_segments": 0}
+    queued = []
 
     def run(mode, x, y, z, leg, q):
         lrm.set_mode(mode)
@@ -94,6 +96,14 @@ def main():
                 m1, d1, b1 = run(lrm.MODE_STRICT if args.exact else lrm.MODE_FAST, t[0], t[1], t[2], leg, q)
                 m2, d2, b2 = run(lrm.MODE_FAST if args.exact else lrm.MODE_TOL, t[0], t[1], t[2], leg, q)
                 torch.cuda.synchronize()
+                if not args.exact:
+                    try:  # how much of the cloud the tolerance kernel handed to the bit-exact fix-up (doubt bands + unanswered table cells)
+                        npts, nq, nover = lrm.dbg_tol_queue_counts()
+                        if npts == len(pts):
+                            queued.append((nq / npts, name))
+                            out["overflowed_segments"] += nover
+                    except lrm.LrmError:
+                        pass
                 if args.exact:  # "error" = 1 for every point with a differing bit pattern (nan == nan)
                     same = (d1.view(torch.int32) == d2.view(torch.int32)) | (torch.isnan(d1) & torch.isnan(d2))
                     err = (~same.all(dim=0)).to(torch.float32)
@@ -119,6 +129,10 @@ def main():
                     print(json.dumps({"violation": {"leg": [float(v) for v in leg], "quat": [float(v) for v in q], "cloud": name,
                                                     "mask": bad_m, "bits": bad_b, "nonfinite": nonfinite, "err": e}}), flush=True)
     lrm.set_mode(lrm.MODE_FAST)
+    if queued:
+        out["max_queued_fraction"] = max(q for q, _ in queued)
+        out["mean_queued_fraction"] = float(np.mean([q for q, _ in queued]))
+        out["mean_queued_fraction_by_cloud"] = {nm: float(np.mean([q for q, k in queued if k == nm])) for nm in sorted({k for _, k in queued})}
     print(json.dumps(out))
     return 1 if (out["mask_mismatches"] or out["bit_word_mismatches"] or out["nonfinite"] or out["max_err"] > tol) else 0
 

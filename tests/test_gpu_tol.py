@@ -220,7 +220,8 @@ def test_tol_far_cloud_uses_the_outer_grid(lrm, oracle, torch_cuda):
     check_outputs(pts, m.cpu().numpy(), None, d.cpu().numpy().T, None, oracle.reach(pts, leg), want_v, want_d, leg)
 
 
-def test_tol_random_legs_orientations_and_boundary_hugging_clouds():
+@pytest.mark.parametrize("table", ["0", "2"])
+def test_tol_random_legs_orientations_and_boundary_hugging_clouds(table):
     """A small instance of tools/stress_tol.py (random leg geometries and joint limits, random orientations; uniform,
     planar, near-axis and boundary-hugging clouds): tolerance mode against the bit-exact mode on the device.  The
     campaigns run while building (profiles/r02_stress_tol.txt): 4.3e9 evaluations, no mask difference; 4.0e-6 with the final settings."""
@@ -229,12 +230,15 @@ def test_tol_random_legs_orientations_and_boundary_hugging_clouds():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # LRM_TOL_TABLE: "0" the staged kernel, "2" the table kernel (a plane table per random leg and orientation) whatever the size
     r = subprocess.run([sys.executable, os.path.join(root, "legged-robot-movability-cuda_amd", "tools", "stress_tol.py"),
-                        "--legs", "8", "--points", "100000", "--seed", "3"], capture_output=True, text=True, timeout=600)
+                        "--legs", "8", "--points", "100000", "--seed", "3"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, LRM_TOL_TABLE=table))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["mask_mismatches"] == 0 and line["bit_word_mismatches"] == 0 and line["max_err"] <= TOL
     assert line["tol_eligible"] >= 12  # most (leg, orientation) pairs do run the tolerance kernels
+    assert line["overflowed_segments"] == 0 or line["mean_queued_fraction_by_cloud"]["uniform"] < 0.05
 
 
 def test_tol_large_cloud_stays_in_its_fast_regime(lrm, torch_cuda):
