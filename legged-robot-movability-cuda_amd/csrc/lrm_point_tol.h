@@ -278,17 +278,23 @@ LRM_HD uint32_t lrm_tt_cell(const uint16_t* cells, uint32_t i) { return cells[i]
 // loads are issued together, then the two fine loads.
 LRM_HD void lrm_toltab_lookup2(const uint16_t* cells, float inv, uint32_t cbase, uint32_t fbase, float x0, float x1, float z,
                                uint32_t& code0, uint32_t& code1) {
-    const float fz = __builtin_fmaf(z, inv, LRM_TT_OFF), fx0 = __builtin_fmaf(x0, inv, LRM_TT_OFF), fx1 = __builtin_fmaf(x1, inv, LRM_TT_OFF);
-    const float gz = __builtin_floorf(fz), gx0 = __builtin_floorf(fx0), gx1 = __builtin_floorf(fx1);
-    const int iz = (int)gz, ix0 = (int)gx0, ix1 = (int)gx1; // saturating conversions, nan -> 0 (a nan point is in doubt already)
+    // position in units of SUB-cells: q = floor(coordinate / cell size * SUB + OFF * SUB); the cell is q >> 4, the sub-cell q & 15
+    // (one FMA, one floor-and-convert, one shift and one mask per coordinate).  The conversion saturates and maps nan to 0 (a
+    // nan point is in doubt already).
+    const float invs = inv * (float)LRM_TT_SUB;
+    constexpr float kOffS = LRM_TT_OFF * (float)LRM_TT_SUB;
+    const int qz = (int)__builtin_floorf(__builtin_fmaf(z, invs, kOffS));
+    const int q0 = (int)__builtin_floorf(__builtin_fmaf(x0, invs, kOffS)), q1 = (int)__builtin_floorf(__builtin_fmaf(x1, invs, kOffS));
+    static_assert(LRM_TT_SUB == 16, "shifts below");
+    const int iz = qz >> 4, ix0 = q0 >> 4, ix1 = q1 >> 4; // arithmetic shifts: a negative position stays negative
     // both indices in [0, N): a negative one sets the sign bit of the OR
     const bool in0 = (uint32_t)(ix0 | iz) < (uint32_t)LRM_TT_N, in1 = (uint32_t)(ix1 | iz) < (uint32_t)LRM_TT_N;
     const uint32_t row = cbase + (uint32_t)(iz * LRM_TT_N);
     const uint32_t a0 = row + (uint32_t)ix0, a1 = row + (uint32_t)ix1;
     const uint32_t c0 = lrm_tt_cell(cells, in0 ? a0 : cbase), c1 = lrm_tt_cell(cells, in1 ? a1 : cbase);
-    // sub-cell inside a refined cell (fx - gx is in [0, 1), exactly)
-    const uint32_t sz = (uint32_t)(int)((fz - gz) * (float)LRM_TT_SUB) * (uint32_t)LRM_TT_SUB + fbase;
-    const uint32_t s0 = sz + (uint32_t)(int)((fx0 - gx0) * (float)LRM_TT_SUB), s1 = sz + (uint32_t)(int)((fx1 - gx1) * (float)LRM_TT_SUB);
+    // sub-cell inside a refined cell
+    const uint32_t sz = ((uint32_t)qz & 15u) * (uint32_t)LRM_TT_SUB + fbase;
+    const uint32_t s0 = sz + ((uint32_t)q0 & 15u), s1 = sz + ((uint32_t)q1 & 15u);
     const bool r0 = (c0 & 0x8000u) != 0u, r1 = (c1 & 0x8000u) != 0u;
     const uint32_t b0 = ((c0 & 0x7fffu) << 8) + s0, b1 = ((c1 & 0x7fffu) << 8) + s1; // LRM_TT_SUB^2 = 256 entries per block
     static_assert(LRM_TT_SUB * LRM_TT_SUB == 256, "fine block size");

@@ -92,3 +92,17 @@ def test_tol_plane_table_vs_oracle(lrm, oracle, legname, az, q, shift):
     both = sure & ((doubt2 & 0xffff) == 0)
     assert np.array_equal(m[both], m2[both])
     assert np.abs(d[both] - d2[both]).max() < 1e-3
+
+
+def test_plane_table_does_not_depend_on_the_builder_threads(lrm, monkeypatch):
+    """the table's rows are classified on several host threads and numbered afterwards, serially: one thread or eight, the
+    same table (same statistics, same answers, same doubt bits).  (The builder is also clean under -fsanitize=thread and
+    -fsanitize=address,undefined on the CPU build.)"""
+    pts = random_cloud(50_000, seed=5)
+    leg = lrm.get_M2_leg(0.9)
+    q = QUATS[2]
+    monkeypatch.setenv("LRM_TOLTAB_THREADS", "1")
+    m1, d1, b1, s1 = lrm.dbg_toltab_host(pts, leg, q)
+    monkeypatch.setenv("LRM_TOLTAB_THREADS", "7")
+    m2, d2, b2, s2 = lrm.dbg_toltab_host(pts, leg, q)
+    assert s1 == s2 and np.array_equal(m1, m2) and np.array_equal(b1, b2) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
