@@ -336,9 +336,15 @@ int lrm_dbg_fast_host(const float* xyz_aos, size_t n, const LrmLegDimensions* le
 int lrm_dbg_tol_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                      uint8_t* mask_out, float* dxyz_aos_out, uint32_t* doubt_out);
 /* As lrm_dbg_tol_host with the plane table with deferred decisions (csrc/lrm_toltab.cpp) in place of the full plane
- * evaluation; doubt bit 0x100 = a cell without an answer.  stats_out[4] (or NULL): rows, validity rows, refined cells, bytes. */
+ * evaluation; doubt bit 0x100 = a cell without an answer.  stats_out[5] (or NULL): rows, validity rows, refined cells, bytes,
+ * points whose second yaw candidate had to be evaluated (its lower bound did not exclude it). */
 int lrm_dbg_toltab_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                         uint8_t* mask_out, float* dxyz_out, uint32_t* doubt_out, uint32_t* stats_out);
+/* The plane table's lower bound of the in-plane distance at n plane points xz[2 n] (abscissa - coxa_length, z), next to the
+ * full plane evaluation there: distance sqrt(du^2 + dz^2), validity, doubt bits.  The bound must not exceed the distance
+ * of an invalid point and must be 0 at a valid one (tests/test_tol_cpu.py). */
+int lrm_dbg_toltab_bounds(const float* xz, size_t n, const LrmLegDimensions* leg, const float* quat, float* lb_out,
+                          float* dist_out, uint8_t* valid_out, uint32_t* doubt_out);
 /* Counting build only (csrc: -DLRM_PAIR_COUNT, tools/c3_evidence.py): what the wave-per-body pair kernel evaluated since the
  * last call: out[0] full (leg, target) evaluations, [1] leg bounding-sphere tests, [2] footholds inside a body's reach sphere,
  * [3] footholds loaded.  LRM_EINVAL in an ordinary build. */

@@ -83,6 +83,7 @@ def load():
         "lrm_dbg_tol_ok": [vp, vp],
         "lrm_dbg_tol_queue_counts": [vp, vp, vp],
         "lrm_dbg_toltab_host": [vp, sz, vp, vp, vp, vp, vp, vp],
+        "lrm_dbg_toltab_bounds": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_shard_bounds": [sz, C.c_int, C.c_int, sz, vp, vp],
         "lrm_dbg_pair_counts": [vp],
         "lrm_tol_prepare": [vp, vp, sz, vp],
@@ -425,10 +426,23 @@ def dbg_toltab_host(xyz, leg, quat=None):
     xyz = _f32(xyz, (-1, 3))
     n = len(xyz)
     mask, d, doubt = np.zeros(n, np.uint8), np.zeros_like(xyz), np.zeros(n, np.uint32)
-    stats = np.zeros(4, np.uint32)
+    stats = np.zeros(5, np.uint32)
     check(load().lrm_dbg_toltab_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d),
                                      _ptr(doubt), _ptr(stats)))
-    return mask, d, doubt, dict(rows=int(stats[0]), vrows=int(stats[1]), refined=int(stats[2]), bytes=int(stats[3]))
+    return mask, d, doubt, dict(rows=int(stats[0]), vrows=int(stats[1]), refined=int(stats[2]), bytes=int(stats[3]),
+                                second_candidates=int(stats[4]))
+
+
+def dbg_toltab_bounds(xz, leg, quat=None):
+    """the plane table's lower bound at plane points (abscissa - coxa_length, z) -> (bound, distance of the full plane
+    evaluation, its validity, its doubt bits)"""
+    xz = _f32(xz, (-1, 2))
+    n = len(xz)
+    lb, dist = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    valid, doubt = np.zeros(n, np.uint8), np.zeros(n, np.uint32)
+    check(load().lrm_dbg_toltab_bounds(_ptr(xz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(lb), _ptr(dist),
+                                       _ptr(valid), _ptr(doubt)))
+    return lb, dist, valid, doubt
 
 
 def dbg_oct_trace(enable):

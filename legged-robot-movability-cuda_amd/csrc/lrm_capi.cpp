@@ -84,8 +84,9 @@ TolEntry& tol_entry(const LrmLegDimensions& leg, const float* quat, const LrmCom
 // where the last tolerance-mode launch left its per-workgroup doubt counts, for lrm_dbg_tol_queue_counts
 struct TolLast {
     int dev = -1;
-    const uint32_t* counts = nullptr; // device: one count per workgroup of the main kernel
-    size_t blocks = 0, n = 0;
+    const uint32_t* counts = nullptr; // device: one count per queue segment of the main kernel
+    size_t blocks = 0, n = 0;         // segments, points
+    uint32_t cap = 0;                 // slots per segment
 } g_tol_last;
 // Device workspace of the doubt queues (rewritten by every call), one per (device, stream) in use, grown on demand.
 struct TolWorkspace {
@@ -161,8 +162,9 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
             else HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, (hipStream_t)stream), "tolerance-mode launch");
             int dev = 0;
             (void)hipGetDevice(&dev);
-            const size_t words = tab ? lrm_tol_tab_queue_words(n) : lrm_tol_queue_words(n);
-            g_tol_last = TolLast{dev, w, words / (4 * LRM_TOL_SEG_CAP_WORDS + 4), n}; // workspace = counts[blocks, padded to 4 * blocks words] | 16-byte records[blocks * cap]
+            // the workspace starts with one count per segment
+            if (tab) g_tol_last = TolLast{dev, w, lrm_tol_tab_segments(n), n, (uint32_t)LRM_TOL_TAB_SEG_CAP};
+            else g_tol_last = TolLast{dev, w, lrm_tol_queue_words(n) / (4 * LRM_TOL_SEG_CAP_WORDS + 4), n, (uint32_t)LRM_TOL_SEG_CAP_WORDS};
             return LRM_OK;
         }
     }
@@ -1012,13 +1014,14 @@ int lrm_dbg_toltab_host(const float* xyz, size_t n, const LrmLegDimensions* leg,
     std::vector<uint8_t> tab;
     if (!lrm_build_tol_tab(TL, &tab)) return fail(LRM_EINVAL, "leg needs more table rows than a cell code can name");
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab.data());
-    const LrmTolTabView G = lrm_toltab_view(tab.data(), hd->rows, hd->vrows);
+    const LrmTolTabView G = lrm_toltab_view(tab.data(), hd->rows, hd->vrows, lrm_toltab_bound_inner(tab.data()));
     if (stats_out) {
         stats_out[0] = hd->n_rows;
         stats_out[1] = hd->n_vrows;
         stats_out[2] = hd->n_fine[0] + hd->n_fine[1];
         stats_out[3] = (uint32_t)tab.size();
     }
+    lrm_tab_host_seconds = 0;
     for (size_t i = 0; i < n; i++) {
         LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
         uint32_t doubt = 0;
@@ -1027,6 +1030,40 @@ int lrm_dbg_toltab_host(const float* xyz, size_t n, const LrmLegDimensions* leg,
         dxyz_out[3 * i + 1] = p.y;
         dxyz_out[3 * i + 2] = p.z;
         doubt_out[i] = doubt;
+    }
+    if (stats_out) stats_out[4] = (uint32_t)std::min<unsigned long long>(lrm_tab_host_seconds, 0xffffffffull);
+    return LRM_OK;
+}
+// The table's lower bound of the in-plane distance at plane points (x = abscissa - coxa_length, z) of the INNER grid, next
+// to what the full plane evaluation (lrm_tol_plane) finds there: tests/test_tol_cpu.py checks bound <= distance.
+int lrm_dbg_toltab_bounds(const float* xz, size_t n, const LrmLegDimensions* leg, const float* quat, float* lb_out,
+                          float* dist_out, uint8_t* valid_out, uint32_t* doubt_out) {
+    if (!leg || (n && (!xz || !lb_out || !dist_out || !valid_out || !doubt_out))) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    LrmTolLeg TL;
+    lrm_compile_tol(L, &TL);
+    if (!TL.tol_ok) return fail(LRM_EINVAL, "leg not eligible for the tolerance mode");
+    std::vector<uint8_t> tab;
+    if (!lrm_build_tol_tab(TL, &tab)) return fail(LRM_EINVAL, "leg needs more table rows than a cell code can name");
+    const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab.data());
+    const LrmTolTabView G = lrm_toltab_view(tab.data(), hd->rows, hd->vrows, lrm_toltab_bound_inner(tab.data()));
+    const LrmTolTables T{&TL.circ[0][0], &TL.feat[0]};
+    for (size_t i = 0; i < n; i++) {
+        const float x = xz[2 * i], z = xz[2 * i + 1];
+        const int g = (std::fabs(x) < G.far_limit && std::fabs(z) < G.far_limit) ? 0 : 1;
+        uint32_t c0, c1;
+        float l0, l1;
+        lrm_toltab_lookup2(G, g != 0, x, x, z, c0, c1, l0, l1);
+        lb_out[i] = l0;
+        const float band = TL.band_base + TL.band_slope * (std::fabs(x) + std::fabs(z)), tau = band * LRM_TOL_TIE;
+        float du, dz;
+        bool valid;
+        uint32_t lu = 0;
+        lrm_tol_plane(TL, T, x + TL.coxa_length, z, band, tau, du, dz, valid, lu);
+        dist_out[i] = std::sqrt(du * du + dz * dz);
+        valid_out[i] = valid;
+        doubt_out[i] = lu;
     }
     return LRM_OK;
 }
@@ -1058,7 +1095,7 @@ int lrm_dbg_tol_queue_counts(uint64_t* n_points, uint64_t* n_queued, uint64_t* n
     uint64_t q = 0, o = 0;
     for (uint32_t v : c) {
         q += v;
-        o += v > (uint32_t)LRM_TOL_SEG_CAP_WORDS;
+        o += v > g_tol_last.cap;
     }
     *n_points = g_tol_last.n;
     *n_queued = q;

@@ -17,6 +17,9 @@ hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const flo
 #define LRM_TOL_SEG_CAP 128 // doubt slots per workgroup of the main kernel (768 points): 17 %.  32 overflowed on the reference's planar bench grid (7 % in doubt: it contains the coxa axis and the symmetry plane)
 #endif
 #define LRM_TOL_SEG_CAP_WORDS LRM_TOL_SEG_CAP
+#ifndef LRM_TOL_TAB_SEG_CAP
+#define LRM_TOL_TAB_SEG_CAP 48 // doubt slots per segment of the table kernel (256 points of one wave): 19 %
+#endif
 size_t lrm_tol_queue_words(size_t n);
 hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, uint8_t* mask,
                                    float* dxyz, uint32_t* workspace, hipStream_t st);
@@ -25,6 +28,7 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
                                uint32_t* workspace, hipStream_t st);
 // Table variant (dist_tab_kernel + the same fix-up): tab_dev = device copy of lrm_build_tol_tab's table for TL.
 size_t lrm_tol_tab_queue_words(size_t n);
+size_t lrm_tol_tab_segments(size_t n); // the workspace starts with one count per segment
 hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                                float* dz, uint32_t* workspace, hipStream_t st);

@@ -248,20 +248,26 @@ struct LrmTolPlaneFull {
 struct LrmTolTabView {
     const LrmTabRow* rows;   // [32]
     const LrmTabVRow* vrows; // [32]
-    const uint16_t* cells;   // the grids' coarse and fine arrays (behind the header)
+    const uint16_t* cells;   // the grids' coarse, fine and bound arrays (behind the header)
+    const uint32_t* bound_inner; // the inner grid's bounds where the caller keeps them (the kernel: its LDS copy; the host: the table's own)
     float band_max, far_limit;
-    float inv_h[2];
-    uint32_t coarse_off[2], fine_off[2];
+    float inv_h[2], lb_unit[2];
+    uint32_t coarse_off[2], fine_off[2], bound_off[2];
 };
-// rows / vrows: where the caller keeps the rows (the kernel: its LDS copy; the host: the header's own)
-LRM_HD LrmTolTabView lrm_toltab_view(const uint8_t* tab, const LrmTabRow* rows, const LrmTabVRow* vrows) {
+// rows / vrows / bound_inner: where the caller keeps them (the kernel: its LDS copies; the host: the table's own)
+LRM_HD LrmTolTabView lrm_toltab_view(const uint8_t* tab, const LrmTabRow* rows, const LrmTabVRow* vrows, const uint32_t* bound_inner) {
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
-    return LrmTolTabView{rows, vrows, reinterpret_cast<const uint16_t*>(tab + sizeof(LrmTolTabHeader)),
-                         hd->band_max, hd->far_limit, {hd->inv_h[0], hd->inv_h[1]}, {hd->coarse_off[0], hd->coarse_off[1]},
-                         {hd->fine_off[0], hd->fine_off[1]}};
+    return LrmTolTabView{rows, vrows, reinterpret_cast<const uint16_t*>(tab + sizeof(LrmTolTabHeader)), bound_inner,
+                         hd->band_max, hd->far_limit, {hd->inv_h[0], hd->inv_h[1]}, {hd->lb_unit[0], hd->lb_unit[1]}, {hd->coarse_off[0], hd->coarse_off[1]},
+                         {hd->fine_off[0], hd->fine_off[1]}, {hd->bound_off[0], hd->bound_off[1]}};
 }
-// cells[i] of the table (global memory).  Device: "uniform base + 32-bit offset" addressing (global_load_ushort with an
-// SGPR base) instead of a 64-bit address per lane.
+// the table's own copy of the inner grid's bounds (host callers)
+inline const uint32_t* lrm_toltab_bound_inner(const uint8_t* tab) {
+    const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
+    return reinterpret_cast<const uint32_t*>(tab + sizeof(LrmTolTabHeader) + 2 * (size_t)hd->bound_off[0]);
+}
+// cells[i] of the table (global memory).  Device: "uniform base + 32-bit offset" addressing (global_load_ushort / _dword with
+// an SGPR base) instead of a 64-bit address per lane.
 #if defined(__HIP_DEVICE_COMPILE__)
 LRM_HD uint32_t lrm_tt_cell(const uint16_t* cells, uint32_t i) {
     typedef const __attribute__((address_space(1))) char* GP;
@@ -270,14 +276,36 @@ LRM_HD uint32_t lrm_tt_cell(const uint16_t* cells, uint32_t i) {
 #endif
     return *(const __attribute__((address_space(1))) uint16_t*)((GP)cells + (i << 1));
 }
+LRM_HD uint32_t lrm_tt_cell32(const uint16_t* cells, uint32_t i) { // the 32-bit word that starts at cells[i], i even
+    typedef const __attribute__((address_space(1))) char* GP;
+    return *(const __attribute__((address_space(1))) uint32_t*)((GP)cells + (i << 1));
+}
+LRM_HD float lrm_half_bits_to_float(uint32_t h) { // the low 16 bits (v_cvt_f32_f16 reads nothing else)
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+}
+LRM_HD int lrm_dot_bytes(uint32_t a, uint32_t b) { return __builtin_amdgcn_sdot4((int)a, (int)b, 0, false); } // sum of the four products of signed bytes
 #else
 LRM_HD uint32_t lrm_tt_cell(const uint16_t* cells, uint32_t i) { return cells[i]; }
+LRM_HD uint32_t lrm_tt_cell32(const uint16_t* cells, uint32_t i) { return (uint32_t)cells[i] | ((uint32_t)cells[i + 1] << 16); }
+LRM_HD float lrm_half_bits_to_float(uint32_t h) { // normal halves and zero only (lrm_toltab.cpp writes nothing else)
+    const uint32_t e = (h >> 10) & 31u, f = h & 1023u;
+    return e == 0u ? 0.f : lrm_u2f(((h & 0x8000u) << 16) | ((e + 112u) << 23) | (f << 13));
+}
+LRM_HD int lrm_dot_bytes(uint32_t a, uint32_t b) {
+    int t = 0;
+    for (int k = 0; k < 4; k++) t += (int)(int8_t)(a >> (8 * k)) * (int)(int8_t)(b >> (8 * k));
+    return t;
+}
 #endif
-// Look-up of two plane points (x0, z), (x1, z) of one point on the grid (inv, cbase, fbase): the codes of their cells, or
-// LRM_TT_UNANSWERED.  Straight-line code: every lane reads one coarse and one fine entry per plane point, the two coarse
-// loads are issued together, then the two fine loads.
-LRM_HD void lrm_toltab_lookup2(const uint16_t* cells, float inv, uint32_t cbase, uint32_t fbase, float x0, float x1, float z,
-                               uint32_t& code0, uint32_t& code1) {
+// Look-up of two plane points (x0, z), (x1, z) of one point on grid `far` (0 inner, 1 outer: the same for the whole wave): the codes
+// of their cells, or LRM_TT_UNANSWERED, and the table's lower bounds of their in-plane distances (0 outside the grid).
+// Straight-line code: every lane reads one coarse and one fine entry per plane point, the two coarse loads are issued together,
+// then the two fine loads; the bounds come from G.bound_inner (LDS in the kernel) or, on the outer grid, from the table.
+LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float x0, float x1, float z,
+                               uint32_t& code0, uint32_t& code1, float& lb0, float& lb1) {
+    const float inv = far ? G.inv_h[1] : G.inv_h[0], unit = far ? G.lb_unit[1] : G.lb_unit[0];
+    const uint32_t cbase = far ? G.coarse_off[1] : G.coarse_off[0], fbase = far ? G.fine_off[1] : G.fine_off[0];
+    const uint16_t* cells = G.cells;
     // position in units of SUB-cells: q = floor(coordinate / cell size * SUB + OFF * SUB); the cell is q >> 4, the sub-cell q & 15
     // (one FMA, one floor-and-convert, one shift and one mask per coordinate).  The conversion saturates and maps nan to 0 (a
     // nan point is in doubt already).
@@ -289,12 +317,13 @@ LRM_HD void lrm_toltab_lookup2(const uint16_t* cells, float inv, uint32_t cbase,
     const int iz = qz >> 4, ix0 = q0 >> 4, ix1 = q1 >> 4; // arithmetic shifts: a negative position stays negative
     // both indices in [0, N): a negative one sets the sign bit of the OR
     const bool in0 = (uint32_t)(ix0 | iz) < (uint32_t)LRM_TT_N, in1 = (uint32_t)(ix1 | iz) < (uint32_t)LRM_TT_N;
-    const uint32_t row = cbase + (uint32_t)(iz * LRM_TT_N);
-    const uint32_t a0 = row + (uint32_t)ix0, a1 = row + (uint32_t)ix1;
-    const uint32_t c0 = lrm_tt_cell(cells, in0 ? a0 : cbase), c1 = lrm_tt_cell(cells, in1 ? a1 : cbase);
+    const uint32_t row = (uint32_t)(iz * LRM_TT_N);
+    const uint32_t a0 = in0 ? row + (uint32_t)ix0 : 0u, a1 = in1 ? row + (uint32_t)ix1 : 0u; // cell number, 0 outside
+    const uint32_t c0 = lrm_tt_cell(cells, cbase + a0), c1 = lrm_tt_cell(cells, cbase + a1);
     // sub-cell inside a refined cell
-    const uint32_t sz = ((uint32_t)qz & 15u) * (uint32_t)LRM_TT_SUB + fbase;
-    const uint32_t s0 = sz + ((uint32_t)q0 & 15u), s1 = sz + ((uint32_t)q1 & 15u);
+    const uint32_t szn = (uint32_t)qz & 15u, sx0 = (uint32_t)q0 & 15u, sx1 = (uint32_t)q1 & 15u;
+    const uint32_t sz = szn * (uint32_t)LRM_TT_SUB + fbase;
+    const uint32_t s0 = sz + sx0, s1 = sz + sx1;
     const bool r0 = (c0 & 0x8000u) != 0u, r1 = (c1 & 0x8000u) != 0u;
     const uint32_t b0 = ((c0 & 0x7fffu) << 8) + s0, b1 = ((c1 & 0x7fffu) << 8) + s1; // LRM_TT_SUB^2 = 256 entries per block
     static_assert(LRM_TT_SUB * LRM_TT_SUB == 256, "fine block size");
@@ -302,6 +331,21 @@ LRM_HD void lrm_toltab_lookup2(const uint16_t* cells, float inv, uint32_t cbase,
     const uint32_t k0 = r0 ? f0 : c0, k1 = r1 ? f1 : c1;
     code0 = in0 ? k0 : (uint32_t)LRM_TT_UNANSWERED;
     code1 = in1 ? k1 : (uint32_t)LRM_TT_UNANSWERED;
+    // the bounds: d0 + unit (gx sx + gz sz), the two products of signed bytes in one v_dot4 (bytes 2 and 3 of the entry)
+    uint32_t e0, e1;
+    if (far) { // wave-uniform
+        e0 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * a0);
+        e1 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * a1);
+    } else {
+        e0 = G.bound_inner[a0];
+        e1 = G.bound_inner[a1];
+    }
+    const uint32_t zb = szn << 24;
+    const float t0 = (float)lrm_dot_bytes(e0, zb | (sx0 << 16)), t1 = (float)lrm_dot_bytes(e1, zb | (sx1 << 16));
+    const float h0 = fmaxf(__builtin_fmaf(t0, unit, lrm_half_bits_to_float(e0)), 0.f);
+    const float h1 = fmaxf(__builtin_fmaf(t1, unit, lrm_half_bits_to_float(e1)), 0.f);
+    lb0 = in0 ? h0 : 0.f;
+    lb1 = in1 ? h1 : 0.f;
 }
 // lrm_tol_plane restricted to what the cell's code names: at most two clamp targets, one circle's point validity.
 // Same arithmetic as lrm_tol_plane on those operands.  x = abscissa - coxa_length.
@@ -352,6 +396,7 @@ LRM_HD void lrm_tol_plane_tab(const LrmTolTabView& G, uint32_t code, float x, fl
     doubt |= lu;
 }
 
+inline thread_local unsigned long long lrm_tab_host_seconds = 0; // host statistic: points whose second candidate was evaluated
 // The whole evaluation of one point with the table: distance_global + reachability_global (one_leg_global.cu:74-130).
 // The flow of lrm_tol_prologue / lrm_tol_candidate / lrm_tol_need_second / lrm_tol_finish, written as one function so
 // that a candidate is carried as (code, du, w, dz) -- the rotation back to the coxa frame is formed once, for the
@@ -385,23 +430,29 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     const bool limD = codeD >= 2u, limF = codeF >= 2u;
     const float wlD = (codeD == 3u) ? wm : wM, wlF = (codeF == 3u) ? wm : wM;
     const float wD = limD ? wlD : 0.f, wF = limF ? wlF : 0.f;
-    const bool nearD = fabsf(wD) <= fabsf(wF);
-    const bool firstD = inD || (!inF && nearD); // a candidate inside the yaw range goes first, else the nearer plane
-    const uint32_t code0 = firstD ? codeD : codeF, code1 = firstD ? codeF : codeD;
-    const float w0 = firstD ? wD : wF, w1 = firstD ? wF : wD;
-    const bool lim0 = code0 >= 2u, lim1 = code1 >= 2u;
-    const float ul0 = (code0 == 3u) ? um : uM, ul1 = (code1 == 3u) ? um : uM;
-    const float ur0 = lrm_u2f(lrm_f2u(r) ^ (code0 << 31)), ur1 = lrm_u2f(lrm_f2u(r) ^ (code1 << 31));
-    const float u0 = lim0 ? ul0 : ur0, u1 = lim1 ? ul1 : ur1;
-    const bool in0 = inD || inF;
+    const float ulD = (codeD == 3u) ? um : uM, ulF = (codeF == 3u) ? um : uM;
+    const float urD = lrm_u2f(lrm_f2u(r) ^ (codeD << 31)), urF = lrm_u2f(lrm_f2u(r) ^ (codeF << 31));
+    const float uD = limD ? ulD : urD, uF = limF ? ulF : urF;
     // Both plane points lie within max(r + coxa_length, |z|) of the femur joint: one grid for both look-ups -- and for the whole
     // wave (the outer grid covers the inner one's area too, with coarser cells): the choice lives on the scalar unit.
     const bool far = LRM_TOL_ANY(!(fmaxf(r + L.coxa_length, fabsf(z)) < G.far_limit));
-    const float inv = far ? G.inv_h[1] : G.inv_h[0];
-    const uint32_t cbase = far ? G.coarse_off[1] : G.coarse_off[0], fbase = far ? G.fine_off[1] : G.fine_off[0];
-    const float x0 = u0 - L.coxa_length, x1 = u1 - L.coxa_length;
-    uint32_t cell0, cell1;
-    lrm_toltab_lookup2(G.cells, inv, cbase, fbase, x0, x1, z, cell0, cell1);
+    const float xD = uD - L.coxa_length, xF = uF - L.coxa_length;
+    uint32_t cellD, cellF;
+    float lbD, lbF;
+    lrm_toltab_lookup2(G, far, xD, xF, z, cellD, cellF, lbD, lbF);
+    // Which candidate first: the one with the smaller lower bound w^2 + lb^2 of its squared distance (lb: the cell's bound of
+    // the in-plane part).  A candidate that may be valid has lb = 0; inside the yaw range (w = 0) its bound is 0 and it goes
+    // first -- the reach flag is always taken from the first candidate.  Equal bounds (the two candidates are one
+    // configuration): the one inside the range.
+    const float bD = __builtin_fmaf(lbD, lbD, wD * wD), bF = __builtin_fmaf(lbF, lbF, wF * wF);
+    const bool firstD = inF ? (bD < bF) : (bD <= bF);
+    const uint32_t code0 = firstD ? codeD : codeF, code1 = firstD ? codeF : codeD;
+    const float w0 = firstD ? wD : wF, w1 = firstD ? wF : wD;
+    const float x0 = firstD ? xD : xF, x1 = firstD ? xF : xD;
+    const uint32_t cell0 = firstD ? cellD : cellF, cell1 = firstD ? cellF : cellD;
+    const float b1 = firstD ? bF : bD;
+    const bool lim0 = code0 >= 2u, lim1 = code1 >= 2u;
+    const bool in0 = firstD ? inD : inF;
     // ---- first candidate ----
     float du0, dz0;
     bool valid0;
@@ -418,28 +469,6 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     }
     const float n0 = __builtin_fmaf(du0, du0, __builtin_fmaf(w0, w0, dz0 * dz0));
     const bool flag = valid0 && in0;
-    // ---- the second one only when it can still win (lrm_tol_need_second) ----
-    bool need;
-    {
-        const float out = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(x1, x1, z * z)) - L.r_outer, 0.f);
-        const float lb = __builtin_fmaf(w1, w1, out * out);
-        const float thr = tau * __builtin_fmaf(2.0f, LRM_FAST_SQRT(n0), tau);
-        need = two && !flag && !(n0 < lb - thr);
-    }
-    float du1 = 0.f, dz1 = 0.f, n1 = 0.f;
-    if (LRM_TOL_ANY(need)) { // device: unless no lane of the wave needs it (a sorted cloud); host: when this point does
-        bool valid1;
-        uint32_t bd = 0;
-        lrm_tol_plane_tab(G, cell1, x1, z, band, tau, du1, dz1, valid1, bd);
-        const float q = __builtin_fmaf(du1, du1, dz1 * dz1), w2 = w1 * w1;
-        const bool lv = lim1 && valid1, big = q > w2 * 9.6e-7f, small = q < w2 * 2.9e-8f;
-        const bool collapse = lv && big;
-        du1 = collapse ? 0.f : du1;
-        dz1 = collapse ? 0.f : dz1;
-        bd |= (lv && !big && !small) ? LRM_TD_LIMIT : 0u;
-        n1 = __builtin_fmaf(du1, du1, __builtin_fmaf(w1, w1, dz1 * dz1));
-        lu |= need ? bd : 0u;
-    }
     // ---- yaw-limit alternative (one_leg.cu:258-274) of a valid first candidate: the nearer limit plane wins when it is closer ----
     uint32_t codeW;
     float duW, wW, dzW;
@@ -459,11 +488,32 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
         dzW = alt ? 0.f : dz0;
         wW = alt ? wL : w0;
     }
-    // ---- distance_circles' pick (one_leg.cu:334): both invalid here (a valid first candidate never asks for the second): the shorter one ----
-    {
+    // ---- the second one only when it can still win: not below its lower bound by more than the tie band ----
+    const bool need = two && !flag && !(n0 < b1 - tau * __builtin_fmaf(2.0f, LRM_FAST_SQRT(n0), tau));
+#if defined(LRM_TAB_EXP_NO_SECOND) // timing experiment (wrong results): the second candidate is never evaluated
+    if (false) {
+#else
+    if (LRM_TOL_ANY(need)) { // device: when a lane of the wave needs it (3 % of the waves of a random cloud); host: when this point does
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+        lrm_tab_host_seconds++;
+#endif
+        float du1, dz1;
+        bool valid1;
+        uint32_t bd = 0;
+        lrm_tol_plane_tab(G, cell1, x1, z, band, tau, du1, dz1, valid1, bd);
+        const float q = __builtin_fmaf(du1, du1, dz1 * dz1), w2 = w1 * w1;
+        const bool lv = lim1 && valid1, big = q > w2 * 9.6e-7f, small = q < w2 * 2.9e-8f;
+        const bool collapse = lv && big;
+        du1 = collapse ? 0.f : du1;
+        dz1 = collapse ? 0.f : dz1;
+        bd |= (lv && !big && !small) ? LRM_TD_LIMIT : 0u;
+        const float n1 = __builtin_fmaf(du1, du1, __builtin_fmaf(w1, w1, dz1 * dz1));
+        // distance_circles' pick (one_leg.cu:334): both invalid here (a valid first candidate never asks for the second): the shorter one
         const float nmin = LRM_FAST_SQRT(fminf(n0, n1));
         const float thr = tau * __builtin_fmaf(2.0f, nmin, tau);
-        lu |= (need && !(fabsf(n0 - n1) > thr)) ? LRM_TD_PICK : 0u;
+        bd |= !(fabsf(n0 - n1) > thr) ? LRM_TD_PICK : 0u;
+        lu |= need ? bd : 0u;
         const bool useB = need && !(n0 < n1);
         codeW = useB ? code1 : codeW;
         duW = useB ? du1 : duW;

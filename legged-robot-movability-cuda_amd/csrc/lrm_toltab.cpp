@@ -48,6 +48,11 @@ struct CellCode {
     int n = 0;
     LrmTabRow t[2];
     LrmTabVRow v;
+    double lb = 0.0; // lower bound of sqrt(du^2 + dz^2) over the cell (set whether or not the cell has an answer)
+    bool all_invalid = false; // every point of the cell is invalid, whatever region list it is evaluated with
+    // coarse cells: the bound as a plane over the sub-cell numbers, d0 + unit (gx sx + gz sz) (linear_bound below)
+    double d0 = 0.0;
+    int gx = 0, gz = 0;
 };
 
 constexpr LrmTabRow kNoneRow{0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 2.f, 0.f};
@@ -118,12 +123,63 @@ CellCode classify_reg(const LrmTolLeg& L, unsigned reg, double cx, double cz, do
         }
     if (out.n == 0) { g_reason = 5; return out; }
     if (out.n == 1) out.t[1] = kNoneRow;
+    // Lower bound of the distance to the chosen target: the choice is one of the survivors, each distance 1-Lipschitz.  A
+    // point that may be valid gets 0 (a candidate on a yaw-limit plane then collapses to its offset).  When no survivor is
+    // available all over the cell the evaluation may find no target at all and return the raw point (one_leg.cu:141-142).
+    {
+        double m = 1.0e30;
+        bool any_always = false;
+        for (int k = 0; k < nc; k++)
+            if (!excl[k]) {
+                m = std::min(m, cand[k].d);
+                any_always = any_always || cand[k].always;
+            }
+        if (!any_always) m = std::min(m, std::hypot(cx, cz));
+        out.lb = vstate == 0 ? std::max(0.0, m - rho) : 0.0;
+        out.all_invalid = vstate == 0;
+    }
     out.v = vstate == 0 ? kFalseRow : (vstate == 1 ? kTrueRow : LrmTabVRow{ct[open_j].x, ct[open_j].y, ct[open_j].gs, ct[open_j].c});
     out.ok = true;
     return out;
 }
 
 bool same_row(const LrmTabRow& a, const LrmTabRow& b) { return std::memcmp(&a, &b, sizeof a) == 0; }
+
+// The bound of a cell without an answer, for the region lists `regs` (bit set): every circle whose clamp point is not
+// proven invalid all over the cell, every corner point, the raw point; 0 where a point may be valid.
+double generic_lb(const LrmTolLeg& L, unsigned regs, double cx, double cz, double rho, double band, double tau) {
+    double lb = std::hypot(cx, cz);
+    bool maybe_valid = false;
+    for (unsigned reg = 0; reg < 4; reg++) {
+        if (!(regs & (1u << reg))) continue;
+        const LrmTolLeg::Circle* ct = &L.circ[reg][0];
+        bool one_out = false;
+        for (int j = 0; j < LRM_N_CIRCLES; j++) {
+            const double vx = cx - ct[j].x, vy = cz - ct[j].y, mag = std::hypot(vx, vy);
+            bool never = false;
+            if (mag > 2.0 * rho) {
+                if (std::fabs((double)ct[j].chw) > 1.0) never = !(ct[j].chw < 0);
+                else {
+                    const double ux = vx / mag, uy = vy / mag;
+                    const double w = vx * (double)ct[j].mx + vy * (double)ct[j].my - (double)ct[j].chw * mag;
+                    const double gx = (double)ct[j].mx - (double)ct[j].chw * ux, gy = (double)ct[j].my - (double)ct[j].chw * uy;
+                    const double lip = std::hypot(gx, gy) + std::fabs((double)ct[j].chw) * rho / (mag - rho);
+                    never = !(w >= 0) && (std::fabs(w) - (double)ct[j].bw * (mag + rho) > tau + lip * rho);
+                }
+            }
+            if (!never) lb = std::min(lb, std::fabs((double)ct[j].r - mag));
+            const double v = (vx * vx + vy * vy) * (double)ct[j].gs + (double)ct[j].c;
+            const double lip = 2.0 * std::fabs((double)ct[j].gs) * (mag + rho) * rho;
+            if (v - lip - band > 0) one_out = true;
+        }
+        if (!one_out) maybe_valid = true;
+    }
+    for (int i = 0; i < L.n_corners; i++) {
+        const LrmCircle& f = L.feat[4 * LRM_N_CIRCLES + i];
+        lb = std::min(lb, std::hypot(cx - f.x, cz - f.y));
+    }
+    return maybe_valid ? 0.0 : std::max(0.0, lb - rho);
+}
 
 // what the cell's points may be evaluated with, or !ok.  Where find_region's rays cross the cell, every region in
 // reach must give the same rows.
@@ -137,15 +193,25 @@ CellCode classify_cell(const LrmTolLeg& L, double cx, double cz, double rho, dou
         if (v[i] < 0) base |= 1u << i;
     }
     CellCode code;
-    unsigned seen = 0;
+    unsigned seen = 0, reach = 0;
+    for (unsigned sub = open_bits;; sub = (sub - 1) & open_bits) { // the region lists in reach
+        reach |= 1u << ((L.region_lut >> (((base & ~open_bits) | sub) << 1)) & 3u);
+        if (sub == 0) break;
+    }
+    const double lb_generic = generic_lb(L, reach, cx, cz, rho, band, tau);
     for (unsigned sub = open_bits;; sub = (sub - 1) & open_bits) { // every assignment of the open signs
         const unsigned pat = (base & ~open_bits) | sub;
         const unsigned reg = (L.region_lut >> (pat << 1)) & 3u;
         if (!(seen & (1u << reg))) {
-            const CellCode c = classify_reg(L, reg, cx, cz, rho, band, tau);
-            if (!c.ok) return c;
+            CellCode c = classify_reg(L, reg, cx, cz, rho, band, tau);
+            if (!c.ok) {
+                c.lb = lb_generic;
+                return c;
+            }
             if (!seen) code = c;
             else {
+                code.lb = std::min(code.lb, c.lb);
+                code.all_invalid = code.all_invalid && c.all_invalid;
                 bool same = c.n == code.n && std::memcmp(&c.v, &code.v, sizeof c.v) == 0;
                 if (same && c.n == 1) same = same_row(c.t[0], code.t[0]);
                 if (same && c.n == 2)
@@ -154,6 +220,7 @@ CellCode classify_cell(const LrmTolLeg& L, double cx, double cz, double rho, dou
                 if (!same) {
                     g_reason = 1;
                     code.ok = false;
+                    code.lb = lb_generic;
                     return code;
                 }
             }
@@ -162,6 +229,50 @@ CellCode classify_cell(const LrmTolLeg& L, double cx, double cz, double rho, dou
         if (sub == 0) break;
     }
     return code;
+}
+
+// The bound of an answered, all-invalid coarse cell as a plane over its sub-cell numbers (sx, sz in 0..SUB-1):
+//     lb = d0 + unit (gx sx + gz sz),  unit = h / 64 mm, gx, gz integers of 8 bits.
+// The evaluation picks one of the cell's targets (or, when none of them is available all over the cell, possibly none: the raw
+// point, one_leg.cu:141-142); the distance to a target is convex outside its circle (the tangent plane bounds it from below) and
+// concave inside (tangent plane minus rho^2 / 2 (|c - c_k| - rho)); a circle that crosses the cell gives no bound.  The plane
+// takes the (quantised) gradient of the nearest target; every target's own plane is lowered by |g_k - g| rho to lie above it.
+// A point of sub-cell (sx, sz) lies in [sx h - slack, (sx + 1) h + slack] x ... : the plane's minimum over that box.
+void linear_bound(const CellCode& c, double cx, double cz, double H, double slack, CellCode* out) {
+    const double h = H / LRM_TT_SUB, rho = 0.5 * H * 1.41421357 + slack, unit = h / 64.0;
+    out->gx = out->gz = 0;
+    out->d0 = c.lb;
+    if (!c.ok || !c.all_invalid) return;
+    struct T { double d, gx, gy, kappa; } t[3];
+    int nt = 0;
+    bool any_always = false;
+    for (int k = 0; k < c.n; k++) {
+        const double vx = cx - c.t[k].x, vy = cz - c.t[k].y, mag = std::hypot(vx, vy), r = c.t[k].r;
+        if (!(mag > 2.0 * rho) || std::fabs(r - mag) <= rho) return; // the constant bound stays
+        const double sgn = mag >= r ? 1.0 : -1.0;
+        t[nt++] = T{std::fabs(r - mag), sgn * vx / mag, sgn * vy / mag, sgn > 0 ? 0.0 : rho * rho / (2.0 * (mag - rho))};
+        any_always = any_always || c.t[k].chw == -2.f;
+    }
+    if (!any_always) {
+        const double mag = std::hypot(cx, cz);
+        if (!(mag > 2.0 * rho)) return;
+        t[nt++] = T{mag, cx / mag, cz / mag, 0.0};
+    }
+    int best = 0;
+    for (int k = 1; k < nt; k++)
+        if (t[k].d < t[best].d) best = k;
+    const int gx = (int)std::lround(t[best].gx * h / unit), gz = (int)std::lround(t[best].gy * h / unit); // |.| <= 64
+    const double qx = gx * unit / h, qz = gz * unit / h; // the gradient in use (per mm)
+    double D = 1.0e30;
+    for (int k = 0; k < nt; k++) D = std::min(D, t[k].d - t[k].kappa - std::hypot(t[k].gx - qx, t[k].gy - qz) * rho);
+    const double half = 0.5 * H;
+    const double d0 = D - half * (qx + qz) + std::min(-qx * slack, qx * (h + slack)) + std::min(-qz * slack, qz * (h + slack));
+    // never below the constant bound everywhere: keep whichever is better at the cell's worst sub-cell
+    const double worst = d0 + unit * (std::min(0, gx) + std::min(0, gz)) * (LRM_TT_SUB - 1);
+    if (worst <= c.lb) return;
+    out->d0 = d0;
+    out->gx = gx;
+    out->gz = gz;
 }
 
 // One grid: N x N cells of H mm around the femur joint, unanswered cells refined into LRM_TT_SUB^2 sub-cells.
@@ -186,15 +297,19 @@ void classify_grid(const LrmTolLeg& L, double H, double band, double tau, int th
             for (int ix = 0; ix < N; ix++) {
                 const double x0 = -half + ix * H, z0 = -half + iz * H;
                 CellCode c = classify_cell(L, x0 + 0.5 * H, z0 + 0.5 * H, 0.5 * H * 1.41421357 + slack, band, tau);
+                linear_bound(c, x0 + 0.5 * H, z0 + 0.5 * H, H, slack, &c);
                 out->coarse[(size_t)iz * N + ix] = c;
                 if (c.ok) continue;
                 std::vector<CellCode> sub((size_t)kSub * kSub);
                 bool any = false;
+                double lb = 1.0e30; // the sub-cells' bounds are tighter than the coarse cell's own: their minimum holds for the whole cell
                 for (int sz = 0; sz < kSub; sz++)
                     for (int sx = 0; sx < kSub; sx++) {
                         sub[(size_t)sz * kSub + sx] = classify_cell(L, x0 + (sx + 0.5) * h, z0 + (sz + 0.5) * h, 0.5 * h * 1.41421357 + slack, band, tau);
                         any = any || sub[(size_t)sz * kSub + sx].ok;
+                        lb = std::min(lb, sub[(size_t)sz * kSub + sx].lb);
                     }
+                out->coarse[(size_t)iz * N + ix].lb = out->coarse[(size_t)iz * N + ix].d0 = std::max(lb, c.lb);
                 if (any) fine_rows[(size_t)iz * N + ix] = std::move(sub);
             }
     };
@@ -209,6 +324,22 @@ void classify_grid(const LrmTolLeg& L, double H, double band, double tau, int th
             out->fine_of[i] = (int)out->fine.size();
             out->fine.push_back(std::move(fine_rows[i]));
         }
+}
+
+// IEEE half (bits) of a bound, rounded DOWN (towards -inf); normal halves and zero only: a positive value below the smallest
+// normal half becomes 0, a negative one above its negative becomes that
+uint16_t half_floor(double v) {
+    const bool neg = v < 0;
+    double a = std::fabs(v);
+    if (!(a >= 6.103515625e-5)) return neg ? 0x8400 : 0;
+    if (a >= 65504.0) a = 65504.0; // (a bound that large does not occur: the grids end at 8192 mm)
+    int e;
+    const double m = std::frexp(a, &e); // a = m 2^e, m in [0.5, 1)
+    const double f = (2.0 * m - 1.0) * 1024.0; // 10 mantissa bits
+    unsigned frac = (unsigned)(neg ? std::ceil(f) : std::floor(f)), ex = (unsigned)(e - 1 + 15);
+    if (frac > 1023u) { frac = 0; ex++; }
+    if (ex > 30u) { ex = 30u; frac = 1023u; }
+    return (uint16_t)((neg ? 0x8000u : 0u) | (ex << 10) | frac);
 }
 
 } // namespace
@@ -257,8 +388,18 @@ bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out) {
             for (const CellCode& c : blk) cells.push_back(code_of(c));
         if (G.fine.empty()) cells.insert(cells.end(), (size_t)kSub * kSub, (uint16_t)LRM_TT_UNANSWERED); // the lookup reads block 0 for unrefined cells
         hd.inv_h[g] = (float)(1.0 / Hs[g]);
+        hd.lb_unit[g] = (float)(Hs[g] / kSub / 64.0);
     }
     if (!rows_ok) return false;
+    for (int g = 0; g < 2; g++) { // 32-bit bounds, little endian: d0, then the gradient bytes
+        if (cells.size() & 1u) cells.push_back(0);
+        hd.bound_off[g] = (uint32_t)cells.size();
+        for (size_t i = 0; i < (size_t)N * N; i++) {
+            const CellCode& c = grids[g].coarse[i];
+            cells.push_back(half_floor(c.d0));
+            cells.push_back((uint16_t)(((unsigned)c.gx & 0xffu) | (((unsigned)c.gz & 0xffu) << 8)));
+        }
+    }
     hd.band_max = (float)band;
     // both plane points of a point lie within max(r + coxa_length, |z|) of the femur joint (|u| <= r)
     hd.far_limit = (float)(0.5 * N * Hs[0] - 1.0);

@@ -8,7 +8,7 @@
 int main(int argc, char** argv) {
     const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 1000000;
     LrmLegDimensions leg;
-    lrm_host_leg_factory(0.f, 181.f, -45.f, 65.5f, 129.f, 135.f, 60.f, 90.f, 120.f, -5.f, -175.f, &leg); // get_M2_leg
+    lrm_host_leg_factory(0.f, 181.f, -45.f, 65.5f, 129.f, 135.f, 60.f, 90.f, 120.f, -5.f, -5.f, &leg); // get_M2_leg
     const float quat[4] = {1, 0, 0, 0};
     LrmCompiledLeg CL;
     lrm_compile_leg(leg, quat, 1, &CL);
