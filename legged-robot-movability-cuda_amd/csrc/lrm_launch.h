@@ -18,7 +18,7 @@ hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const flo
 #endif
 #define LRM_TOL_SEG_CAP_WORDS LRM_TOL_SEG_CAP
 #ifndef LRM_TOL_TAB_SEG_CAP
-#define LRM_TOL_TAB_SEG_CAP 48 // doubt slots per segment of the table kernel (256 points of one wave): 19 %
+#define LRM_TOL_TAB_SEG_CAP 256 // doubt slots per workgroup of the table kernel (1536 points): 17 %
 #endif
 size_t lrm_tol_queue_words(size_t n);
 hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, uint8_t* mask,

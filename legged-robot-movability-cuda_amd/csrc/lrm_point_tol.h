@@ -331,17 +331,21 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float x0, float
     const uint32_t k0 = r0 ? f0 : c0, k1 = r1 ? f1 : c1;
     code0 = in0 ? k0 : (uint32_t)LRM_TT_UNANSWERED;
     code1 = in1 ? k1 : (uint32_t)LRM_TT_UNANSWERED;
-    // the bounds: d0 + unit (gx sx + gz sz), the two products of signed bytes in one v_dot4 (bytes 2 and 3 of the entry)
+    // the bounds: one entry per 2 x 2 coarse cells, d0 + unit (gx sx + gz sz) over its 16 x 16 sub-cells, the two products of
+    // signed bytes in one v_dot4 (bytes 2 and 3 of the entry)
+    static_assert(LRM_TT_N == 2 * LRM_TT_NB, "bound cell = 2 x 2 coarse cells = 32 sub-cell units");
+    const uint32_t rowb = (uint32_t)((qz >> 5) * LRM_TT_NB);
+    const uint32_t g0 = in0 ? rowb + (uint32_t)(q0 >> 5) : 0u, g1 = in1 ? rowb + (uint32_t)(q1 >> 5) : 0u;
     uint32_t e0, e1;
     if (far) { // wave-uniform
-        e0 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * a0);
-        e1 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * a1);
+        e0 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * g0);
+        e1 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * g1);
     } else {
-        e0 = G.bound_inner[a0];
-        e1 = G.bound_inner[a1];
+        e0 = G.bound_inner[g0];
+        e1 = G.bound_inner[g1];
     }
-    const uint32_t zb = szn << 24;
-    const float t0 = (float)lrm_dot_bytes(e0, zb | (sx0 << 16)), t1 = (float)lrm_dot_bytes(e1, zb | (sx1 << 16));
+    const uint32_t zb = (((uint32_t)qz >> 1) & 15u) << 24;
+    const float t0 = (float)lrm_dot_bytes(e0, zb | ((((uint32_t)q0 >> 1) & 15u) << 16)), t1 = (float)lrm_dot_bytes(e1, zb | ((((uint32_t)q1 >> 1) & 15u) << 16));
     const float h0 = fmaxf(__builtin_fmaf(t0, unit, lrm_half_bits_to_float(e0)), 0.f);
     const float h1 = fmaxf(__builtin_fmaf(t1, unit, lrm_half_bits_to_float(e1)), 0.f);
     lb0 = in0 ? h0 : 0.f;

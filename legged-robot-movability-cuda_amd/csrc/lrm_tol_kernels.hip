@@ -293,82 +293,85 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
 // Table variant (LrmTolTabHeader, lrm_toltab.cpp): the plane evaluation of a yaw candidate is ONE look-up in the
 // plane table with deferred decisions plus the reduced evaluation of what the cell names (lrm_tol_plane_tab: two
 // clamp targets, one circle's validity), and the table's lower bounds decide which candidate is evaluated -- the
-// second one in 0.3 % of the points.  No workgroup stage, no barriers in the loop.  A point whose cell carries no
-// answer is queued with the doubtful ones for the bit-exact fix-up.
+// second one in 0.3 % of the points (17 % of the waves of a random cloud).  No workgroup stage, no barriers in the
+// loop.  A point whose cell carries no answer is queued with the doubtful ones for the bit-exact fix-up.
 //   Memory: the cell codes (32 KB coarse per grid + 512 B per refined cell) stay in global memory -- read by every
-// workgroup of every launch, they live in the L1 / L2; the rows (1.5 KB) and the inner grid's bounds (64 KB) are staged in
-// LDS: a wave's scattered look-up costs 8 cycles of its CU there against 110-140 in a 128-512 KB table in global memory
-// (tools/gather_rates.hip), and with the bounds in global memory the kernel was bound by exactly that.
-//   Geometry: 64 KB of LDS per workgroup allow two workgroups per CU, so a workgroup has kTabThreads = 768 threads
-// (6 waves per SIMD) and is PERSISTENT: 2 x CUs workgroups, each staging the bounds once and taking a contiguous chunk of
-// `rpw` rounds of 768 points.  Doubt queue: one segment per (wave, epoch of kTabEpoch rounds) = 256 points, slot numbers
-// from a wave-private counter -- no LDS atomics, no barrier; the wave stores a segment's count when the epoch ends.
+// workgroup of every launch, they live in the L1 / L2; the rows (1.5 KB) and the inner grid's bounds (16 KB) are staged
+// in LDS by every workgroup: a wave's scattered look-up costs 8 cycles of its CU there, 42 in a table the L1 holds,
+// 110-140 in one of 128-512 KB (tools/gather_rates.hip) -- with 16 mm bound cells in global memory (256 KB with the
+// codes) the kernel was bound by exactly that, at 80 us.
+//   Tried (profiles/r03_ab_tab_persistent.txt): bounds per coarse cell (64 KB of LDS) in PERSISTENT workgroups of 768
+// threads, two per CU, work items taken from an LDS counter: 83-87 us.  The hardware issues the oldest wave first, so
+// the first workgroup of a CU runs ahead and leaves the second one the CU at half occupancy for the last 20 us (wave
+// priorities that fall with a workgroup's progress: -4 %); with small workgroups the dispatcher back-fills instead.
 // ------------------------------------------------------------------------------------------------------------
 #ifndef LRM_TAB_MIN_WAVES
-#define LRM_TAB_MIN_WAVES 6 // two workgroups of 12 waves per CU
+#define LRM_TAB_MIN_WAVES 7 // at 8 waves (64 VGPRs) the compiler spills
 #endif
-#ifndef LRM_TAB_THREADS
-#define LRM_TAB_THREADS 768
+#ifndef LRM_TAB_GRID_MULT
+#define LRM_TAB_GRID_MULT 8
 #endif
-#ifndef LRM_TAB_EPOCH
-#define LRM_TAB_EPOCH 4
-#endif
-constexpr int kTabThreads = LRM_TAB_THREADS, kTabWaves = kTabThreads / 64, kTabEpoch = LRM_TAB_EPOCH;
-constexpr int kTabSegCap = LRM_TOL_TAB_SEG_CAP; // doubt slots per segment (256 points)
-constexpr uint32_t kTabBoundBytes = LRM_TT_N * LRM_TT_N * 4;
-static_assert(kTabThreads % 64 == 0 && kTabBoundBytes % 16 == 0, "whole waves, 16-byte staging");
 struct TabLds {
     LrmTabRow rows[32];
     LrmTabVRow vrows[32];
 };
-// rpw: rounds per workgroup; segment number of (workgroup, epoch, wave) = (workgroup * n_epochs + epoch) * kTabWaves + wave
+constexpr int kTabSegCap = LRM_TOL_TAB_SEG_CAP; // doubt slots per workgroup of dist_tab_kernel
+constexpr int kTabBoundVecs = LRM_TT_NB * LRM_TT_NB * 4 / 16; // 16-byte pieces of the inner grid's bounds
+static_assert(kTabBoundVecs % kBlock == 0, "every thread stages the same number of pieces");
 template <int kOp, bool kAoS = false>
-__global__ __launch_bounds__(kTabThreads, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
+__global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ tab, QueueRec* __restrict__ queue,
-    uint32_t* __restrict__ counts, uint32_t rpw, uint32_t n_epochs, uint32_t selftest) {
+    uint32_t* __restrict__ counts, uint32_t selftest) {
     __shared__ TabLds s_tab;
-    extern __shared__ uint32_t s_bound[]; // LRM_TT_N^2 bounds of the inner grid
+    __shared__ uint32_t s_bound[LRM_TT_NB * LRM_TT_NB];
+    __shared__ uint32_t s_qn;
     const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
-    const size_t chunk0 = (size_t)blockIdx.x * rpw * kTabThreads; // first point of this workgroup
     LrmVec3 p_next{0.f, 0.f, 0.f}; // the first point in front of the table staging
     {
-        const size_t i0 = chunk0 + threadIdx.x;
+        const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x;
+        const size_t rb0 = (size_t)blockIdx.x * kBlock;
         const uint32_t to = lrm_opaque(threadIdx.x * 4u);
-        if (i0 < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * chunk0, 3u * to), lrm_at(x + 3 * chunk0, 3u * to + 4u), lrm_at(x + 3 * chunk0, 3u * to + 8u)}
-                                  : LrmVec3{lrm_at(x + chunk0, to), lrm_at(y + chunk0, to), lrm_at(z + chunk0, to)};
+        if (i0 < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb0, 3u * to), lrm_at(x + 3 * rb0, 3u * to + 4u), lrm_at(x + 3 * rb0, 3u * to + 8u)}
+                                  : LrmVec3{lrm_at(x + rb0, to), lrm_at(y + rb0, to), lrm_at(z + rb0, to)};
     }
     {
         static_assert(sizeof(TabLds) == sizeof(hd->rows) + sizeof(hd->vrows) && sizeof(TabLds) % 16 == 0, "rows | vrows");
         const uint4* src = reinterpret_cast<const uint4*>(&hd->rows[0]);
-        for (int i = threadIdx.x; i < (int)(sizeof(TabLds) / 16); i += kTabThreads) reinterpret_cast<uint4*>(&s_tab)[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(TabLds) / 16); i += kBlock) reinterpret_cast<uint4*>(&s_tab)[i] = src[i];
+        // the bounds: a thread's loads in flight together (a loop of load - wait - store costs one L2 round trip per pass)
         const uint4* bsrc = reinterpret_cast<const uint4*>(tab + sizeof(LrmTolTabHeader) + 2 * (size_t)hd->bound_off[0]);
-        for (int i = threadIdx.x; i < (int)(kTabBoundBytes / 16); i += kTabThreads) reinterpret_cast<uint4*>(s_bound)[i] = bsrc[i];
+        uint4 v[kTabBoundVecs / kBlock];
+#pragma unroll
+        for (int k = 0; k < kTabBoundVecs / kBlock; k++) v[k] = bsrc[k * kBlock + (int)threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < kTabBoundVecs / kBlock; k++) reinterpret_cast<uint4*>(s_bound)[k * kBlock + (int)threadIdx.x] = v[k];
+        if (threadIdx.x == 0) s_qn = 0;
         __syncthreads();
     }
     const LrmTolTabView G = lrm_toltab_view(tab, s_tab.rows, s_tab.vrows, s_bound);
 #if defined(LRM_FIX_TRACE)
     if (threadIdx.x == 0 && blockIdx.x < 32768) g_main_trace[blockIdx.x * 2] = wall_clock64();
 #endif
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t n_pad = (uint32_t)((n + 63) & ~(size_t)63); // whole waves iterate together (ballots below)
+    QueueRec* seg = queue + (size_t)blockIdx.x * kTabSegCap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t toff0 = threadIdx.x * 4u;
-    uint32_t qn = 0;      // doubtful points of this wave in the current epoch (wave-uniform)
-    uint32_t ep_done = 0; // epochs whose count this wave has stored
-    for (uint32_t round = 0; round < rpw; round++) {
-        const size_t rbase = chunk0 + (size_t)round * kTabThreads;
-        if (rbase + (size_t)wave * 64 >= n) break; // nothing left for this wave (wave-uniform; later rounds lie further out)
-        const size_t i = rbase + threadIdx.x;
+    uint32_t round = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride, round++) {
         const bool live = i < n;
+        const size_t rbase = (size_t)blockIdx.x * kBlock + (size_t)round * stride;
         const uint32_t toff = lrm_opaque(toff0), tid_o = lrm_opaque(threadIdx.x);
         LrmVec3 p = p_next;
         {   // the next round's point is in flight while this one is evaluated
-            const size_t rb_next = rbase + kTabThreads;
+            const uint32_t i_next = i + stride;
+            const size_t rb_next = rbase + stride;
             p_next = LrmVec3{0.f, 0.f, 0.f};
-            if (round + 1 < rpw && i + kTabThreads < n)
-                p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
-                              : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
+            if (i_next < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
+                                          : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
         }
         uint32_t doubt = 0;
         const bool m = lrm_tab_point(L, G, p, doubt) && live;
@@ -389,31 +392,23 @@ __global__ __launch_bounds__(kTabThreads, LRM_TAB_MIN_WAVES) void dist_tab_kerne
             const uint64_t w = __ballot(m);
             if (lane == 0) lrm_at(bits + (rbase >> 6), lrm_opaque((uint32_t)wave * 8u)) = w;
         }
-        const uint32_t epoch = round / kTabEpoch;
-        const size_t segno = ((size_t)blockIdx.x * n_epochs + epoch) * kTabWaves + wave;
         const uint64_t dm = __ballot(doubt != 0);
         if (dm) {
+            uint32_t qb = 0;
+            if (lane == 0) qb = atomicAdd(&s_qn, (uint32_t)__popcll(dm));
+            qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
             if (doubt) {
-                const uint32_t qs = qn + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
-                if (qs < (uint32_t)kTabSegCap) { // beyond: the count tells the fix-up to redo the segment.  The point comes back from the L2 (loaded a round ago)
+                const uint32_t qs = qb + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+                if (qs < (uint32_t)kTabSegCap) { // beyond: the count tells the fix-up to redo the workgroup.  The point comes back from the L2 (loaded a round ago)
                     const LrmVec3 q = kAoS ? LrmVec3{lrm_at(x + 3 * rbase, 3u * toff), lrm_at(x + 3 * rbase, 3u * toff + 4u), lrm_at(x + 3 * rbase, 3u * toff + 8u)}
                                            : LrmVec3{lrm_at(x + rbase, toff), lrm_at(y + rbase, toff), lrm_at(z + rbase, toff)};
-                    queue[segno * kTabSegCap + qs] = QueueRec{(uint32_t)i, q.x, q.y, q.z};
+                    seg[qs] = QueueRec{i, q.x, q.y, q.z};
                 }
             }
-            qn += (uint32_t)__popcll(dm);
-        }
-        // the epoch ends with this round, or the wave has nothing behind it
-        const bool last = (round + 1) % kTabEpoch == 0 || round + 1 == rpw || rbase + kTabThreads + (size_t)wave * 64 >= n;
-        if (last) {
-            if (lane == 0) counts[segno] = qn;
-            qn = 0;
-            ep_done = epoch + 1;
         }
     }
-    // counts are rewritten by every call: the segments this wave never reached hold nothing
-    if (lane == 0)
-        for (uint32_t e = ep_done; e < n_epochs; e++) counts[((size_t)blockIdx.x * n_epochs + e) * kTabWaves + wave] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
 #if defined(LRM_FIX_TRACE)
     if (threadIdx.x == 0 && blockIdx.x < 32768) g_main_trace[blockIdx.x * 2 + 1] = wall_clock64();
 #endif
@@ -491,17 +486,14 @@ struct FixLds {
     LrmCircle corners[LRM_N_CORNERS];
 };
 
-// One workgroup: the segments [blockIdx.x * kSegPerWave, +kSegPerWave) of the `nseg` segments of a main-kernel launch.
-// Which points a segment stands for (only needed when it overflowed and all of them are redone):
-//   tab_rpw == 0 (dist_tol_staged_kernel): segment = workgroup s, points s * kBlock + t + round * main_stride;
-//   tab_rpw != 0 (dist_tab_kernel): segment = (workgroup, epoch, wave), see there.
+// One workgroup: the segments [blockIdx.x * kSegPerWave, +kSegPerWave) of the `nseg` segments (= workgroups) of a main-kernel
+// launch with grid stride `main_stride` points; seg_cap slots per segment.
 template <int kOp, bool kAoS = false, int kSegPerWave = LRM_TOL_SEG_PER_WAVE>
 __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const QueueRec* __restrict__ queue,
-    const uint32_t* __restrict__ counts, uint32_t nseg, uint32_t seg_cap, size_t main_stride, uint32_t tab_rpw, uint32_t tab_epochs,
-    uint32_t selftest) {
+    const uint32_t* __restrict__ counts, uint32_t nseg, uint32_t seg_cap, size_t main_stride, uint32_t selftest) {
     __shared__ FixLds s_tab;
     __shared__ uint32_t s_pre[kSegPerWave + 1], s_cnt[kSegPerWave];
     constexpr uint32_t kQueueAhead = kFixBlock / kSegPerWave;
@@ -591,34 +583,16 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
 #endif
     for (int j = 0; j < kSegPerWave; j++) {
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[j]) <= seg_cap) continue; // wave-uniform, and known to be
-        // one pass = kPerPass = 64 consecutive points; every lane of the workgroup comes through every pass
-        static_assert(kPerPass == 64 && kBlock % kPerPass == 0, "whole passes");
-        const size_t sj = (size_t)seg0 + j;
-        size_t first, step_minor, step_major, passes; // pass q: points first + (q % minor) * step_minor + (q / minor) * step_major + [0, 64)
-        uint32_t minor;
-        if (tab_rpw == 0) { // every point of workgroup sj: i = sj * kBlock + t + round * main_stride
-            if (main_stride == 0) continue;
-            minor = kBlock / kPerPass;
-            first = sj * kBlock;
-            step_minor = kPerPass;
-            step_major = main_stride;
-            passes = first < n ? ((n - first + main_stride - 1) / main_stride) * minor : 0;
-        } else { // the rounds of epoch e of wave w of workgroup g
-            const size_t w = sj % kTabWaves, t = sj / kTabWaves, e = t % tab_epochs, g = t / tab_epochs;
-            const uint32_t r0 = (uint32_t)e * kTabEpoch;
-            minor = 1;
-            first = (g * tab_rpw + r0) * kTabThreads + w * 64;
-            step_minor = 0;
-            step_major = kTabThreads;
-            passes = r0 < tab_rpw ? std::min<uint32_t>(kTabEpoch, tab_rpw - r0) : 0;
-        }
-        for (size_t q = 0; q < passes; q++) { // workgroup-uniform trip count
-            const size_t i = first + (q % minor) * step_minor + (q / minor) * step_major + slot;
-            const bool live = i < n;
-            LrmVec3 p{300.f, 0.f, -100.f};
-            if (live) p = kAoS ? LrmVec3{x[3 * i], x[3 * i + 1], x[3 * i + 2]} : LrmVec3{x[i], y[i], z[i]};
-            redo(i, p, live);
-        }
+        // every point of workgroup seg0 + j: i = (seg0 + j) * kBlock + t + round * main_stride
+        if (main_stride == 0) continue;
+        for (size_t base = (size_t)(seg0 + j) * kBlock; base < n; base += main_stride)
+            for (int t0 = 0; t0 < kBlock; t0 += kPerPass) { // workgroup-uniform trip count: kBlock / kPerPass passes for every lane
+                const size_t i = base + t0 + slot;
+                const bool live = i < n;
+                LrmVec3 p{300.f, 0.f, -100.f};
+                if (live) p = kAoS ? LrmVec3{x[3 * i], x[3 * i + 1], x[3 * i + 2]} : LrmVec3{x[i], y[i], z[i]};
+                redo(i, p, live);
+            }
     }
 }
 
@@ -659,66 +633,44 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
     const size_t stride = blocks * kBlock;
-    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, 0u, 0u, tol_selftest());
-    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, 0u, 0u, tol_selftest());
+    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
+    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
     return hipGetLastError();
 }
 
-// Table variant: tab_dev = the device copy of lrm_build_tol_tab's table for TL.  Same fix-up; the geometry of dist_tab_kernel:
-// `wgs` persistent workgroups (two per CU) of `rpw` rounds of kTabThreads points each, segments of kTabEpoch rounds of one wave.
-#ifndef LRM_TAB_WG_PER_CU
-#define LRM_TAB_WG_PER_CU 2
+// Table variant: tab_dev = the device copy of lrm_build_tol_tab's table for TL.  Same workspace layout and fix-up as above, with
+// kTabSegCap slots per workgroup.
+#ifndef LRM_TAB_ROUNDS
+#define LRM_TAB_ROUNDS 6 // rounds of a workgroup on large clouds (it stages 17.5 KB of tables once): its doubt segment (kTabSegCap slots) then holds 17 % of its points
 #endif
 #ifndef LRM_TAB_FIX_SEGS
-#define LRM_TAB_FIX_SEGS 16 // segments per fix-up workgroup: ~20 queued points at the usual 0.5 % of doubt, one pass
+#define LRM_TAB_FIX_SEGS 8 // segments per fix-up workgroup: ~60 queued points at the usual 0.5 % of doubt, 1000 workgroups (4 segments, 2000 workgroups: 3 us slower)
 #endif
-struct TabGeometry {
-    uint32_t wgs, rpw, n_epochs;
-    size_t segments;
-};
-static TabGeometry tab_geometry(size_t n) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        else cus = 256;
-    }
-    const size_t rounds = std::max<size_t>(1, (n + kTabThreads - 1) / kTabThreads);
-    const size_t slots = (size_t)cus * LRM_TAB_WG_PER_CU;
-    TabGeometry g;
-    g.rpw = (uint32_t)((rounds + slots - 1) / slots);
-    g.wgs = (uint32_t)((rounds + g.rpw - 1) / g.rpw);
-    g.n_epochs = (g.rpw + kTabEpoch - 1) / kTabEpoch;
-    g.segments = (size_t)g.wgs * g.n_epochs * kTabWaves;
-    return g;
+static size_t tab_main_blocks(size_t n) {
+    const size_t base = (size_t)256 * LRM_TAB_MIN_WAVES * LRM_TAB_GRID_MULT; // workgroups of four waves: every resident slot LRM_TAB_GRID_MULT times over
+    const size_t need = (n + kBlock - 1) / kBlock;
+    size_t blocks = std::max(base, (need + LRM_TAB_ROUNDS - 1) / LRM_TAB_ROUNDS);
+    if (blocks > need) blocks = need;
+    if (blocks == 0) blocks = 1;
+    return blocks;
 }
-// counts[segments] (padded to a multiple of 4 words) | 16-byte records[segments * kTabSegCap]
-size_t lrm_tol_tab_queue_words(size_t n) {
-    const size_t segs = tab_geometry(n).segments;
-    return ((segs + 3) & ~(size_t)3) + segs * 4 * (size_t)kTabSegCap;
-}
-size_t lrm_tol_tab_segments(size_t n) { return tab_geometry(n).segments; }
+size_t lrm_tol_tab_queue_words(size_t n) { return tab_main_blocks(n) * (4 * (size_t)kTabSegCap + 4); }
+size_t lrm_tol_tab_segments(size_t n) { return tab_main_blocks(n); }
 template <int kOp, bool kAoS>
 static hipError_t launch_tab(const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL,
                              const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace,
                              hipStream_t st) {
-    if (n > 0xffffffffull - 2 * kTabThreads) return hipErrorInvalidValue; // queue records carry 32-bit point numbers
-    static bool attr_done = false; // per instantiation
-    if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dist_tab_kernel<kOp, kAoS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTabBoundBytes);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    const TabGeometry g = tab_geometry(n);
+    const size_t blocks = tab_main_blocks(n);
     uint32_t* counts = workspace;
-    QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + ((g.segments + 3) & ~(size_t)3)); // 16-byte aligned behind the counts
-    hipLaunchKernelGGL((dist_tab_kernel<kOp, kAoS>), dim3(g.wgs), dim3(kTabThreads), kTabBoundBytes, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue,
-                       counts, g.rpw, g.n_epochs, tol_selftest());
+    QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
+    hipLaunchKernelGGL((dist_tab_kernel<kOp, kAoS>), dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts,
+                       tol_selftest());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const unsigned fblocks = (unsigned)((g.segments + LRM_TAB_FIX_SEGS - 1) / LRM_TAB_FIX_SEGS);
+    const unsigned fblocks = (unsigned)((blocks + LRM_TAB_FIX_SEGS - 1) / LRM_TAB_FIX_SEGS);
+    const size_t stride = blocks * kBlock;
     hipLaunchKernelGGL((tol_fixup_kernel<kOp, kAoS, LRM_TAB_FIX_SEGS>), dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts,
-                       (uint32_t)g.segments, (uint32_t)kTabSegCap, (size_t)0, g.rpw, g.n_epochs, tol_selftest());
+                       (uint32_t)blocks, (uint32_t)kTabSegCap, stride, tol_selftest());
     return hipGetLastError();
 }
 hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
@@ -745,7 +697,7 @@ hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const Lrm
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
     const size_t stride = blocks * kBlock;
-    if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, 0u, 0u, tol_selftest());
-    else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, 0u, 0u, tol_selftest());
+    if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
+    else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
     return hipGetLastError();
 }

@@ -50,9 +50,6 @@ struct CellCode {
     LrmTabVRow v;
     double lb = 0.0; // lower bound of sqrt(du^2 + dz^2) over the cell (set whether or not the cell has an answer)
     bool all_invalid = false; // every point of the cell is invalid, whatever region list it is evaluated with
-    // coarse cells: the bound as a plane over the sub-cell numbers, d0 + unit (gx sx + gz sz) (linear_bound below)
-    double d0 = 0.0;
-    int gx = 0, gz = 0;
 };
 
 constexpr LrmTabRow kNoneRow{0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 2.f, 0.f};
@@ -231,48 +228,18 @@ CellCode classify_cell(const LrmTolLeg& L, double cx, double cz, double rho, dou
     return code;
 }
 
-// The bound of an answered, all-invalid coarse cell as a plane over its sub-cell numbers (sx, sz in 0..SUB-1):
-//     lb = d0 + unit (gx sx + gz sz),  unit = h / 64 mm, gx, gz integers of 8 bits.
-// The evaluation picks one of the cell's targets (or, when none of them is available all over the cell, possibly none: the raw
-// point, one_leg.cu:141-142); the distance to a target is convex outside its circle (the tangent plane bounds it from below) and
-// concave inside (tangent plane minus rho^2 / 2 (|c - c_k| - rho)); a circle that crosses the cell gives no bound.  The plane
-// takes the (quantised) gradient of the nearest target; every target's own plane is lowered by |g_k - g| rho to lie above it.
-// A point of sub-cell (sx, sz) lies in [sx h - slack, (sx + 1) h + slack] x ... : the plane's minimum over that box.
-void linear_bound(const CellCode& c, double cx, double cz, double H, double slack, CellCode* out) {
-    const double h = H / LRM_TT_SUB, rho = 0.5 * H * 1.41421357 + slack, unit = h / 64.0;
-    out->gx = out->gz = 0;
-    out->d0 = c.lb;
-    if (!c.ok || !c.all_invalid) return;
-    struct T { double d, gx, gy, kappa; } t[3];
-    int nt = 0;
+// Lower bound of the distance to the target the evaluation picks at a point within rho of (cx, cz), for a cell with an answer
+// whose points are all invalid: the choice is one of the cell's targets (or, when none of them is available all over the cell,
+// possibly none: the raw point, one_leg.cu:141-142), each distance 1-Lipschitz.
+double survivor_lb(const CellCode& c, double cx, double cz, double rho) {
+    double m = 1.0e30;
     bool any_always = false;
     for (int k = 0; k < c.n; k++) {
-        const double vx = cx - c.t[k].x, vy = cz - c.t[k].y, mag = std::hypot(vx, vy), r = c.t[k].r;
-        if (!(mag > 2.0 * rho) || std::fabs(r - mag) <= rho) return; // the constant bound stays
-        const double sgn = mag >= r ? 1.0 : -1.0;
-        t[nt++] = T{std::fabs(r - mag), sgn * vx / mag, sgn * vy / mag, sgn > 0 ? 0.0 : rho * rho / (2.0 * (mag - rho))};
+        m = std::min(m, std::fabs((double)c.t[k].r - std::hypot(cx - c.t[k].x, cz - c.t[k].y)));
         any_always = any_always || c.t[k].chw == -2.f;
     }
-    if (!any_always) {
-        const double mag = std::hypot(cx, cz);
-        if (!(mag > 2.0 * rho)) return;
-        t[nt++] = T{mag, cx / mag, cz / mag, 0.0};
-    }
-    int best = 0;
-    for (int k = 1; k < nt; k++)
-        if (t[k].d < t[best].d) best = k;
-    const int gx = (int)std::lround(t[best].gx * h / unit), gz = (int)std::lround(t[best].gy * h / unit); // |.| <= 64
-    const double qx = gx * unit / h, qz = gz * unit / h; // the gradient in use (per mm)
-    double D = 1.0e30;
-    for (int k = 0; k < nt; k++) D = std::min(D, t[k].d - t[k].kappa - std::hypot(t[k].gx - qx, t[k].gy - qz) * rho);
-    const double half = 0.5 * H;
-    const double d0 = D - half * (qx + qz) + std::min(-qx * slack, qx * (h + slack)) + std::min(-qz * slack, qz * (h + slack));
-    // never below the constant bound everywhere: keep whichever is better at the cell's worst sub-cell
-    const double worst = d0 + unit * (std::min(0, gx) + std::min(0, gz)) * (LRM_TT_SUB - 1);
-    if (worst <= c.lb) return;
-    out->d0 = d0;
-    out->gx = gx;
-    out->gz = gz;
+    if (!any_always) m = std::min(m, std::hypot(cx, cz));
+    return std::max(0.0, m - rho);
 }
 
 // One grid: N x N cells of H mm around the femur joint, unanswered cells refined into LRM_TT_SUB^2 sub-cells.
@@ -297,7 +264,6 @@ void classify_grid(const LrmTolLeg& L, double H, double band, double tau, int th
             for (int ix = 0; ix < N; ix++) {
                 const double x0 = -half + ix * H, z0 = -half + iz * H;
                 CellCode c = classify_cell(L, x0 + 0.5 * H, z0 + 0.5 * H, 0.5 * H * 1.41421357 + slack, band, tau);
-                linear_bound(c, x0 + 0.5 * H, z0 + 0.5 * H, H, slack, &c);
                 out->coarse[(size_t)iz * N + ix] = c;
                 if (c.ok) continue;
                 std::vector<CellCode> sub((size_t)kSub * kSub);
@@ -309,7 +275,7 @@ void classify_grid(const LrmTolLeg& L, double H, double band, double tau, int th
                         any = any || sub[(size_t)sz * kSub + sx].ok;
                         lb = std::min(lb, sub[(size_t)sz * kSub + sx].lb);
                     }
-                out->coarse[(size_t)iz * N + ix].lb = out->coarse[(size_t)iz * N + ix].d0 = std::max(lb, c.lb);
+                out->coarse[(size_t)iz * N + ix].lb = std::max(lb, c.lb);
                 if (any) fine_rows[(size_t)iz * N + ix] = std::move(sub);
             }
     };
@@ -324,6 +290,69 @@ void classify_grid(const LrmTolLeg& L, double H, double band, double tau, int th
             out->fine_of[i] = (int)out->fine.size();
             out->fine.push_back(std::move(fine_rows[i]));
         }
+}
+
+// The bounds of one grid: LRM_TT_NB^2 bound cells of 2 H, each a plane over its 16 x 16 sub-cells (size hs = H / 8),
+//     lb(sx, sz) = d0 + unit (gx sx + gz sz),  unit = hs / 64 mm, gx, gz integers of 8 bits.
+// A sub-cell's own bound comes from the coarse cell it lies in: the distance to that cell's targets at the sub-cell's centre
+// minus its half-diagonal (cells with an answer and no valid point), the minimum over the fine sub-cells it covers (refined
+// cells), else the coarse cell's constant.  The plane: least-squares gradient, quantised, then lowered until no sub-cell's
+// bound lies below it -- nothing to prove about curvature.
+struct BoundEntry {
+    double d0;
+    int gx, gz;
+};
+void build_bounds(const GridCells& G, double H, int threads, std::vector<BoundEntry>* out) {
+    constexpr int N = LRM_TT_N, NB = LRM_TT_NB, kSub = LRM_TT_SUB, S = 16;
+    static_assert(N == 2 * NB, "a bound cell is 2 x 2 coarse cells");
+    const double half = 0.5 * N * H, hs = 2.0 * H / S, slack = H * 1.6e-5 + 1.0e-3, rho = 0.5 * hs * 1.41421357 + slack, unit = hs / 64.0;
+    out->assign((size_t)NB * NB, BoundEntry{0.0, 0, 0});
+    auto work = [&](int t) {
+        for (int bz = t; bz < NB; bz += threads)
+            for (int bx = 0; bx < NB; bx++) {
+                double lb[S][S];
+                for (int sz = 0; sz < S; sz++)
+                    for (int sx = 0; sx < S; sx++) {
+                        const double cx = -half + bx * 2.0 * H + (sx + 0.5) * hs, cz = -half + bz * 2.0 * H + (sz + 0.5) * hs;
+                        const int ix = 2 * bx + sx / (S / 2), iz = 2 * bz + sz / (S / 2);
+                        const size_t ci = (size_t)iz * N + ix;
+                        const CellCode& c = G.coarse[ci];
+                        double v;
+                        if (c.ok) v = c.all_invalid ? survivor_lb(c, cx, cz, rho) : 0.0;
+                        else if (G.fine_of[ci] >= 0) { // the 2 x 2 fine sub-cells this sub-cell covers
+                            const std::vector<CellCode>& f = G.fine[(size_t)G.fine_of[ci]];
+                            const int fx = (sx % (S / 2)) * (kSub / (S / 2)), fz = (sz % (S / 2)) * (kSub / (S / 2));
+                            v = 1.0e30;
+                            for (int a = 0; a < kSub / (S / 2); a++)
+                                for (int b = 0; b < kSub / (S / 2); b++) v = std::min(v, f[(size_t)(fz + a) * kSub + fx + b].lb);
+                        } else v = c.lb;
+                        lb[sz][sx] = v;
+                    }
+                double mean = 0, gx = 0, gz = 0;
+                for (int sz = 0; sz < S; sz++)
+                    for (int sx = 0; sx < S; sx++) mean += lb[sz][sx];
+                mean /= S * S;
+                const double m = 0.5 * (S - 1), var = S * (S * S - 1.0) / 12.0 * S; // sum over the grid of (s - m)^2
+                for (int sz = 0; sz < S; sz++)
+                    for (int sx = 0; sx < S; sx++) {
+                        gx += (sx - m) * (lb[sz][sx] - mean);
+                        gz += (sz - m) * (lb[sz][sx] - mean);
+                    }
+                BoundEntry e;
+                e.gx = (int)std::lround(std::max(-127.0, std::min(127.0, gx / var / unit)));
+                e.gz = (int)std::lround(std::max(-127.0, std::min(127.0, gz / var / unit)));
+                e.d0 = 1.0e30;
+                for (int sz = 0; sz < S; sz++)
+                    for (int sx = 0; sx < S; sx++) e.d0 = std::min(e.d0, lb[sz][sx] - unit * (e.gx * sx + e.gz * sz));
+                (*out)[(size_t)bz * NB + bx] = e;
+            }
+    };
+    if (threads <= 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
 }
 
 // IEEE half (bits) of a bound, rounded DOWN (towards -inf); normal halves and zero only: a positive value below the smallest
@@ -388,16 +417,17 @@ bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out) {
             for (const CellCode& c : blk) cells.push_back(code_of(c));
         if (G.fine.empty()) cells.insert(cells.end(), (size_t)kSub * kSub, (uint16_t)LRM_TT_UNANSWERED); // the lookup reads block 0 for unrefined cells
         hd.inv_h[g] = (float)(1.0 / Hs[g]);
-        hd.lb_unit[g] = (float)(Hs[g] / kSub / 64.0);
+        hd.lb_unit[g] = (float)(2.0 * Hs[g] / 16.0 / 64.0);
     }
     if (!rows_ok) return false;
     for (int g = 0; g < 2; g++) { // 32-bit bounds, little endian: d0, then the gradient bytes
+        std::vector<BoundEntry> bounds;
+        build_bounds(grids[g], Hs[g], threads, &bounds);
         if (cells.size() & 1u) cells.push_back(0);
         hd.bound_off[g] = (uint32_t)cells.size();
-        for (size_t i = 0; i < (size_t)N * N; i++) {
-            const CellCode& c = grids[g].coarse[i];
-            cells.push_back(half_floor(c.d0));
-            cells.push_back((uint16_t)(((unsigned)c.gx & 0xffu) | (((unsigned)c.gz & 0xffu) << 8)));
+        for (const BoundEntry& e : bounds) {
+            cells.push_back(half_floor(e.d0));
+            cells.push_back((uint16_t)(((unsigned)e.gx & 0xffu) | (((unsigned)e.gz & 0xffu) << 8)));
         }
     }
     hd.band_max = (float)band;

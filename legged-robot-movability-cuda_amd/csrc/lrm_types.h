@@ -172,15 +172,16 @@ struct LrmTolLeg {
 // Lipschitz bounds.  With 16 mm cells refined once to 4 mm, 99.3 % of the plane evaluations of the config-2 cloud
 // are answered (the first-generation table: 92.8 %); the rest go to the bit-exact fix-up like any doubtful point.
 //   layout: LrmTolTabHeader | uint16 cells[]: per grid (inner, outer) coarse[LRM_TT_N^2] and fine[LRM_TT_SUB^2 * max(n_fine, 1)],
-//           then per grid bound[LRM_TT_N^2] (32 bits each, at an even index)
+//           then per grid bound[LRM_TT_NB^2] (32 bits each, at an even index)
 //   coarse: bit 15 set: refined, bits 0-14 = fine block;  else a cell code
-//   bound:  {d0 (IEEE half), gx (int8), gz (int8)}: max(0, d0 + lb_unit (gx sx + gz sz)) is a LOWER BOUND (mm) of the in-plane
-//           part sqrt(du^2 + dz^2) of a yaw candidate's distance for every plane point of sub-cell (sx, sz) of the coarse cell -- 0
-//           wherever a point may be valid.  The per-point code orders the two yaw candidates by w^2 + bound^2, takes the reach flag
-//           from the first and skips the second when the first one's distance is below the other's bound (the round-2 bound,
-//           "beyond the outer circle", left the second evaluation to 26 % of the points of a random cloud, that is to every wave;
-//           this one to 0.3 %).  The kernel keeps the inner grid's bounds (64 KB) in LDS: a wave's scattered look-up costs 8 cycles
-//           of its CU there, 110-140 in a table of 128-512 KB in global memory (tools/gather_rates.hip).
+//   bound:  one entry per BOUND CELL = 2 x 2 coarse cells (32 mm inner, 256 mm outer), {d0 (IEEE half), gx (int8), gz (int8)}:
+//           max(0, d0 + lb_unit (gx sx + gz sz)) is a LOWER BOUND (mm) of the in-plane part sqrt(du^2 + dz^2) of a yaw candidate's
+//           distance for every plane point of sub-cell (sx, sz), 16 x 16 per bound cell -- 0 wherever a point may be valid.  The
+//           per-point code orders the two yaw candidates by w^2 + bound^2, takes the reach flag from the first and skips the second
+//           when the first one's distance is below the other's bound (the round-2 bound, "beyond the outer circle", left the second
+//           evaluation to 26 % of the points of a random cloud, that is to every wave; this one to 0.2 %).  The kernel keeps the
+//           inner grid's bounds (16 KB) in LDS: a wave's scattered look-up costs 8 cycles of its CU there, 42 in a table the L1
+//           holds and 110-140 in one of 128-512 KB (tools/gather_rates.hip).
 //   code (15 bits): target A (row, 5 bits) | target B (row, 5 bits) << 5 | validity row (5 bits) << 10;
 //                   LRM_TT_UNANSWERED = 0x7fff: no answer (rows 31 never exist)
 //   rows[]:  a clamp target {x, y, r, corner | mx, my, chw, bw}: `corner` = 3e38 for a corner point (it only competes when
@@ -194,6 +195,7 @@ struct LrmTolLeg {
 #endif
 #define LRM_TT_H_INNER 16.0f   // inner grid: 16 mm cells (1 mm refined) over +-1024 mm around the femur joint
 #define LRM_TT_H_OUTER 128.0f  // outer grid: 128 mm cells (8 mm refined) over +-8192 mm: points the inner grid does not cover
+#define LRM_TT_NB 64          // bound cells per axis (two coarse cells each)
 #define LRM_TT_UNANSWERED 0x7fffu
 #define LRM_TT_MAX_ROWS 31
 struct alignas(16) LrmTabRow {
@@ -209,7 +211,7 @@ struct LrmTolTabHeader {
     uint32_t fine_off[2];   // ... of each grid's fine blocks (block 0 of a grid without refined cells is a spare)
     float inv_h[2];         // 1 / cell size (mm)
     uint32_t bound_off[2];  // ... (even) of each grid's array of 32-bit bounds
-    float lb_unit[2];       // the unit of a bound's gradient bytes: sub-cell size / 64 (mm)
+    float lb_unit[2];       // the unit of a bound's gradient bytes: (bound cell / 16) / 64 mm
     float band_max;         // the table holds for points whose decision band (mm) is at most this
     float far_limit;        // a point with max(r + coxa_length, |z|) below this has both plane points on the inner grid
     uint32_t n_rows, n_vrows;
