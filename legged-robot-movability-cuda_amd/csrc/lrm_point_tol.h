@@ -307,21 +307,29 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float x0, float
     const uint32_t cbase = far ? G.coarse_off[1] : G.coarse_off[0], fbase = far ? G.fine_off[1] : G.fine_off[0];
     const uint16_t* cells = G.cells;
     // position in units of SUB-cells: q = floor(coordinate / cell size * SUB + OFF * SUB); the cell is q >> 4, the sub-cell q & 15
-    // (one FMA, one floor-and-convert, one shift and one mask per coordinate).  The conversion saturates and maps nan to 0 (a
-    // nan point is in doubt already).
+    // (one FMA, one conversion, one shift and one mask per coordinate).  On the inner grid every plane point lies inside (`far`
+    // is false when max(r + coxa_length, |z|) < far_limit for every lane): positions are positive, truncation is floor, no range
+    // test.  On the outer grid a position is clamped into the grid and the point marked (-> unanswered, bound 0); nan fails the
+    // test too (the conversion maps it to 0).
     const float invs = inv * (float)LRM_TT_SUB;
-    constexpr float kOffS = LRM_TT_OFF * (float)LRM_TT_SUB;
-    const int qz = (int)__builtin_floorf(__builtin_fmaf(z, invs, kOffS));
-    const int q0 = (int)__builtin_floorf(__builtin_fmaf(x0, invs, kOffS)), q1 = (int)__builtin_floorf(__builtin_fmaf(x1, invs, kOffS));
+    constexpr float kOffS = LRM_TT_OFF * (float)LRM_TT_SUB, kMaxS = (float)(LRM_TT_N * LRM_TT_SUB) - 0.5f;
+    float pz = __builtin_fmaf(z, invs, kOffS), p0 = __builtin_fmaf(x0, invs, kOffS), p1 = __builtin_fmaf(x1, invs, kOffS);
+    bool out0 = false, out1 = false;
+    if (far) { // wave-uniform
+        const bool oz = !(pz >= 0.f && pz <= kMaxS);
+        out0 = oz || !(p0 >= 0.f && p0 <= kMaxS);
+        out1 = oz || !(p1 >= 0.f && p1 <= kMaxS);
+        pz = fminf(fmaxf(pz, 0.f), kMaxS);
+        p0 = fminf(fmaxf(p0, 0.f), kMaxS);
+        p1 = fminf(fmaxf(p1, 0.f), kMaxS);
+    }
+    const uint32_t qz = (uint32_t)(int)pz, q0 = (uint32_t)(int)p0, q1 = (uint32_t)(int)p1; // >= 0: truncation is floor
     static_assert(LRM_TT_SUB == 16, "shifts below");
-    const int iz = qz >> 4, ix0 = q0 >> 4, ix1 = q1 >> 4; // arithmetic shifts: a negative position stays negative
-    // both indices in [0, N): a negative one sets the sign bit of the OR
-    const bool in0 = (uint32_t)(ix0 | iz) < (uint32_t)LRM_TT_N, in1 = (uint32_t)(ix1 | iz) < (uint32_t)LRM_TT_N;
-    const uint32_t row = (uint32_t)(iz * LRM_TT_N);
-    const uint32_t a0 = in0 ? row + (uint32_t)ix0 : 0u, a1 = in1 ? row + (uint32_t)ix1 : 0u; // cell number, 0 outside
+    const uint32_t row = (qz >> 4) * (uint32_t)LRM_TT_N;
+    const uint32_t a0 = row + (q0 >> 4), a1 = row + (q1 >> 4); // cell numbers
     const uint32_t c0 = lrm_tt_cell(cells, cbase + a0), c1 = lrm_tt_cell(cells, cbase + a1);
     // sub-cell inside a refined cell
-    const uint32_t szn = (uint32_t)qz & 15u, sx0 = (uint32_t)q0 & 15u, sx1 = (uint32_t)q1 & 15u;
+    const uint32_t szn = qz & 15u, sx0 = q0 & 15u, sx1 = q1 & 15u;
     const uint32_t sz = szn * (uint32_t)LRM_TT_SUB + fbase;
     const uint32_t s0 = sz + sx0, s1 = sz + sx1;
     const bool r0 = (c0 & 0x8000u) != 0u, r1 = (c1 & 0x8000u) != 0u;
@@ -329,13 +337,13 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float x0, float
     static_assert(LRM_TT_SUB * LRM_TT_SUB == 256, "fine block size");
     const uint32_t f0 = lrm_tt_cell(cells, r0 ? b0 : fbase), f1 = lrm_tt_cell(cells, r1 ? b1 : fbase);
     const uint32_t k0 = r0 ? f0 : c0, k1 = r1 ? f1 : c1;
-    code0 = in0 ? k0 : (uint32_t)LRM_TT_UNANSWERED;
-    code1 = in1 ? k1 : (uint32_t)LRM_TT_UNANSWERED;
+    code0 = k0;
+    code1 = k1;
     // the bounds: one entry per 2 x 2 coarse cells, d0 + unit (gx sx + gz sz) over its 16 x 16 sub-cells, the two products of
     // signed bytes in one v_dot4 (bytes 2 and 3 of the entry)
     static_assert(LRM_TT_N == 2 * LRM_TT_NB, "bound cell = 2 x 2 coarse cells = 32 sub-cell units");
-    const uint32_t rowb = (uint32_t)((qz >> 5) * LRM_TT_NB);
-    const uint32_t g0 = in0 ? rowb + (uint32_t)(q0 >> 5) : 0u, g1 = in1 ? rowb + (uint32_t)(q1 >> 5) : 0u;
+    const uint32_t rowb = (qz >> 5) * (uint32_t)LRM_TT_NB;
+    const uint32_t g0 = rowb + (q0 >> 5), g1 = rowb + (q1 >> 5);
     uint32_t e0, e1;
     if (far) { // wave-uniform
         e0 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * g0);
@@ -344,12 +352,18 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float x0, float
         e0 = G.bound_inner[g0];
         e1 = G.bound_inner[g1];
     }
-    const uint32_t zb = (((uint32_t)qz >> 1) & 15u) << 24;
-    const float t0 = (float)lrm_dot_bytes(e0, zb | ((((uint32_t)q0 >> 1) & 15u) << 16)), t1 = (float)lrm_dot_bytes(e1, zb | ((((uint32_t)q1 >> 1) & 15u) << 16));
+    const uint32_t zb = ((qz >> 1) & 15u) << 24;
+    const float t0 = (float)lrm_dot_bytes(e0, zb | (((q0 >> 1) & 15u) << 16)), t1 = (float)lrm_dot_bytes(e1, zb | (((q1 >> 1) & 15u) << 16));
     const float h0 = fmaxf(__builtin_fmaf(t0, unit, lrm_half_bits_to_float(e0)), 0.f);
     const float h1 = fmaxf(__builtin_fmaf(t1, unit, lrm_half_bits_to_float(e1)), 0.f);
-    lb0 = in0 ? h0 : 0.f;
-    lb1 = in1 ? h1 : 0.f;
+    lb0 = h0;
+    lb1 = h1;
+    if (far) {
+        code0 = out0 ? (uint32_t)LRM_TT_UNANSWERED : code0;
+        code1 = out1 ? (uint32_t)LRM_TT_UNANSWERED : code1;
+        lb0 = out0 ? 0.f : lb0;
+        lb1 = out1 ? 0.f : lb1;
+    }
 }
 // lrm_tol_plane restricted to what the cell's code names: at most two clamp targets, one circle's point validity.
 // Same arithmetic as lrm_tol_plane on those operands.  x = abscissa - coxa_length.
@@ -387,16 +401,21 @@ LRM_HD void lrm_tol_plane_tab(const LrmTolTabView& G, uint32_t code, float x, fl
     // (the winner's distance itself is |r - mag|; when even the winner is an invalid clamp, lo2 is huge and the point in doubt)
     const float a = fabsf(wina ? da : db);
     const float tie_thr = __builtin_fmaf(lo2, 4.0e-6f, __builtin_fmaf(tau, __builtin_fmaf(2.0f, a, tau), lo2));
-    const float vx = wina ? ax : bx, vy = wina ? ay : by, m = wina ? ma : mb, rs = wina ? rsa : rsb, r = wina ? ra.r : rb.r;
-    const float s = __builtin_fmaf(-r, rs, 1.0f);
+    const float vx = wina ? ax : bx, vy = wina ? ay : by, rs = wina ? rsa : rsb, r = wina ? ra.r : rb.r;
+    const float s = __builtin_fmaf(-r, rs, 1.0f); // 1 - r / |p - c|
     du = vx * s;
     dz = vy * s;
     uint32_t lu = 0;
+    // An unanswered cell names validity row 31, which lrm_toltab.cpp fills with nan: vacc is nan and fails this test.
     lu |= !(fabsf(vacc) > band) ? LRM_TD_REGION : 0u;
     lu |= !(cacc > tau) ? LRM_TD_CLAMP : 0u;
     lu |= !(hi2 > tie_thr) ? LRM_TD_TIE : 0u;
-    lu |= (!(lo2 < 1.0e30f) || !(m * LRM_TOL_AMP2 > r * r)) ? LRM_TD_NONE : 0u;
-    lu |= (code == (uint32_t)LRM_TT_UNANSWERED) ? LRM_TD_AMBIG : 0u;
+    // the amplification guard of lrm_tol_plane, |p - c|^2 AMP2 > r^2, as r / |p - c| < sqrt(AMP2): 1 - s < 8
+    static_assert(LRM_TOL_AMP2 == 64.0f, "s > 1 - sqrt(AMP2)");
+    lu |= (!(lo2 < 1.0e30f) || !(s > -7.0f)) ? LRM_TD_NONE : 0u;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    lu |= (code == (uint32_t)LRM_TT_UNANSWERED) ? LRM_TD_AMBIG : 0u; // host statistic (the device needs no test of its own: see above)
+#endif
     doubt |= lu;
 }
 

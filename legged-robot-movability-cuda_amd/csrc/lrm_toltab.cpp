@@ -437,6 +437,8 @@ bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out) {
     hd.n_vrows = (uint32_t)R.vrows.size();
     for (size_t i = 0; i < 32; i++) hd.rows[i] = i < R.rows.size() ? R.rows[i] : kNoneRow;
     for (size_t i = 0; i < 32; i++) hd.vrows[i] = i < R.vrows.size() ? R.vrows[i] : kFalseRow;
+    // LRM_TT_UNANSWERED names row 31 three times: its validity is nan, which no test passes (lrm_tol_plane_tab: doubt)
+    hd.vrows[31] = LrmTabVRow{0.f, 0.f, 0.f, std::nanf("")};
     out->resize(sizeof hd + cells.size() * 2);
     std::memcpy(out->data(), &hd, sizeof hd);
     std::memcpy(out->data() + sizeof hd, cells.data(), cells.size() * 2);
