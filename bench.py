@@ -589,7 +589,7 @@ def main():
     if rank == 0:
         total_evals = float(n_total) * args.steps
         achieved = BYTES_PER_EVAL["reach_dist"] * n / (kernel_ms * 1e-3) / 1e9
-        kname = {"tol": "dist_tab_kernel<2, false> + tol_fixup_kernel<2, false> (one step = both launches)",
+        kname = {"tol": "dist_tab_kernel<2, false> + tol_fixup_kernel<2, false, 8> (one step = both launches)",
                  "fast": "dist_soa_kernel<2, true>", "strict": "dist_soa_kernel<2, false>"}[args.mode]
         prof = committed_profile(n, args.mode)
         roofline = {

@@ -1014,7 +1014,7 @@ int lrm_dbg_toltab_host(const float* xyz, size_t n, const LrmLegDimensions* leg,
     std::vector<uint8_t> tab;
     if (!lrm_build_tol_tab(TL, &tab)) return fail(LRM_EINVAL, "leg needs more table rows than a cell code can name");
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab.data());
-    const LrmTolTabView G = lrm_toltab_view(tab.data(), hd->rows, hd->vrows, lrm_toltab_bound_inner(tab.data()));
+    const LrmTolTabView G = lrm_toltab_view(tab.data(), hd->rows, hd->vrows, lrm_toltab_bound_inner(tab.data()), TL.r_outer);
     if (stats_out) {
         stats_out[0] = hd->n_rows;
         stats_out[1] = hd->n_vrows;
@@ -1047,7 +1047,7 @@ int lrm_dbg_toltab_bounds(const float* xz, size_t n, const LrmLegDimensions* leg
     std::vector<uint8_t> tab;
     if (!lrm_build_tol_tab(TL, &tab)) return fail(LRM_EINVAL, "leg needs more table rows than a cell code can name");
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab.data());
-    const LrmTolTabView G = lrm_toltab_view(tab.data(), hd->rows, hd->vrows, lrm_toltab_bound_inner(tab.data()));
+    const LrmTolTabView G = lrm_toltab_view(tab.data(), hd->rows, hd->vrows, lrm_toltab_bound_inner(tab.data()), TL.r_outer);
     const LrmTolTables T{&TL.circ[0][0], &TL.feat[0]};
     for (size_t i = 0; i < n; i++) {
         const float x = xz[2 * i], z = xz[2 * i + 1];

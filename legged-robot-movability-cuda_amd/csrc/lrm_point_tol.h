@@ -91,6 +91,9 @@
 #endif
 #define LRM_TD_SECOND 0x10000u // statistic only: the second candidate could not be pruned by its lower bound
 
+#ifndef LRM_TAB_FAR_BOUNDS
+#define LRM_TAB_FAR_BOUNDS 0 // 1: the outer grid's bounds come from the table (global memory) instead of the outer circle
+#endif
 #ifndef LRM_TOL_DIET
 #define LRM_TOL_DIET 1
 #endif
@@ -253,13 +256,14 @@ struct LrmTolTabView {
     float band_max, far_limit;
     float inv_h[2], lb_unit[2];
     uint32_t coarse_off[2], fine_off[2], bound_off[2];
+    float r_outer; // every clamp target and every valid point lies within this of the femur joint (LrmTolLeg::r_outer)
 };
 // rows / vrows / bound_inner: where the caller keeps them (the kernel: its LDS copies; the host: the table's own)
-LRM_HD LrmTolTabView lrm_toltab_view(const uint8_t* tab, const LrmTabRow* rows, const LrmTabVRow* vrows, const uint32_t* bound_inner) {
+LRM_HD LrmTolTabView lrm_toltab_view(const uint8_t* tab, const LrmTabRow* rows, const LrmTabVRow* vrows, const uint32_t* bound_inner, float r_outer) {
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
     return LrmTolTabView{rows, vrows, reinterpret_cast<const uint16_t*>(tab + sizeof(LrmTolTabHeader)), bound_inner,
                          hd->band_max, hd->far_limit, {hd->inv_h[0], hd->inv_h[1]}, {hd->lb_unit[0], hd->lb_unit[1]}, {hd->coarse_off[0], hd->coarse_off[1]},
-                         {hd->fine_off[0], hd->fine_off[1]}, {hd->bound_off[0], hd->bound_off[1]}};
+                         {hd->fine_off[0], hd->fine_off[1]}, {hd->bound_off[0], hd->bound_off[1]}, r_outer};
 }
 // the table's own copy of the inner grid's bounds (host callers)
 inline const uint32_t* lrm_toltab_bound_inner(const uint8_t* tab) {
@@ -339,25 +343,32 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float x0, float
     const uint32_t k0 = r0 ? f0 : c0, k1 = r1 ? f1 : c1;
     code0 = k0;
     code1 = k1;
-    // the bounds: one entry per 2 x 2 coarse cells, d0 + unit (gx sx + gz sz) over its 16 x 16 sub-cells, the two products of
-    // signed bytes in one v_dot4 (bytes 2 and 3 of the entry)
+    // The bounds.  Inner grid: one entry per 2 x 2 coarse cells, d0 + unit (gx sx + gz sz) over its 16 x 16 sub-cells, the two
+    // products of signed bytes in one v_dot4 (bytes 2 and 3 of the entry), from LDS.  Outer grid (LRM_TAB_FAR_BOUNDS 0): the
+    // distance beyond the circle that holds every target and every valid point -- far from the workspace that is nearly the
+    // distance itself, and it costs no look-up (the table's outer bounds, read from global memory, made a far cloud 10 % slower
+    // than this: profiles/r03_ab_far_bounds.txt).
     static_assert(LRM_TT_N == 2 * LRM_TT_NB, "bound cell = 2 x 2 coarse cells = 32 sub-cell units");
     const uint32_t rowb = (qz >> 5) * (uint32_t)LRM_TT_NB;
     const uint32_t g0 = rowb + (q0 >> 5), g1 = rowb + (q1 >> 5);
-    uint32_t e0, e1;
-    if (far) { // wave-uniform
-        e0 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * g0);
-        e1 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * g1);
-    } else {
-        e0 = G.bound_inner[g0];
-        e1 = G.bound_inner[g1];
-    }
     const uint32_t zb = ((qz >> 1) & 15u) << 24;
-    const float t0 = (float)lrm_dot_bytes(e0, zb | (((q0 >> 1) & 15u) << 16)), t1 = (float)lrm_dot_bytes(e1, zb | (((q1 >> 1) & 15u) << 16));
-    const float h0 = fmaxf(__builtin_fmaf(t0, unit, lrm_half_bits_to_float(e0)), 0.f);
-    const float h1 = fmaxf(__builtin_fmaf(t1, unit, lrm_half_bits_to_float(e1)), 0.f);
-    lb0 = h0;
-    lb1 = h1;
+    if (far && !LRM_TAB_FAR_BOUNDS) { // wave-uniform
+        const float zz = z * z;
+        lb0 = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(x0, x0, zz)) - G.r_outer, 0.f);
+        lb1 = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(x1, x1, zz)) - G.r_outer, 0.f);
+    } else {
+        uint32_t e0, e1;
+        if (far) {
+            e0 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * g0);
+            e1 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * g1);
+        } else {
+            e0 = G.bound_inner[g0];
+            e1 = G.bound_inner[g1];
+        }
+        const float t0 = (float)lrm_dot_bytes(e0, zb | (((q0 >> 1) & 15u) << 16)), t1 = (float)lrm_dot_bytes(e1, zb | (((q1 >> 1) & 15u) << 16));
+        lb0 = fmaxf(__builtin_fmaf(t0, unit, lrm_half_bits_to_float(e0)), 0.f);
+        lb1 = fmaxf(__builtin_fmaf(t1, unit, lrm_half_bits_to_float(e1)), 0.f);
+    }
     if (far) {
         code0 = out0 ? (uint32_t)LRM_TT_UNANSWERED : code0;
         code1 = out1 ? (uint32_t)LRM_TT_UNANSWERED : code1;

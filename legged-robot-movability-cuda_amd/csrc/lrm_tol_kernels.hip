@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
         if (threadIdx.x == 0) s_qn = 0;
         __syncthreads();
     }
-    const LrmTolTabView G = lrm_toltab_view(tab, s_tab.rows, s_tab.vrows, s_bound);
+    const LrmTolTabView G = lrm_toltab_view(tab, s_tab.rows, s_tab.vrows, s_bound, L.r_outer);
 #if defined(LRM_FIX_TRACE)
     if (threadIdx.x == 0 && blockIdx.x < 32768) g_main_trace[blockIdx.x * 2] = wall_clock64();
 #endif
