@@ -480,12 +480,11 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     // configuration): the one inside the range.
     const float bD = __builtin_fmaf(lbD, lbD, wD * wD), bF = __builtin_fmaf(lbF, lbF, wF * wF);
     const bool firstD = inF ? (bD < bF) : (bD <= bF);
-    const uint32_t code0 = firstD ? codeD : codeF, code1 = firstD ? codeF : codeD;
-    const float w0 = firstD ? wD : wF, w1 = firstD ? wF : wD;
-    const float x0 = firstD ? xD : xF, x1 = firstD ? xF : xD;
-    const uint32_t cell0 = firstD ? cellD : cellF, cell1 = firstD ? cellF : cellD;
+    const uint32_t code0 = firstD ? codeD : codeF;
+    const float w0 = firstD ? wD : wF, x0 = firstD ? xD : xF;
+    const uint32_t cell0 = firstD ? cellD : cellF;
     const float b1 = firstD ? bF : bD;
-    const bool lim0 = code0 >= 2u, lim1 = code1 >= 2u;
+    const bool lim0 = code0 >= 2u;
     const bool in0 = firstD ? inD : inF;
     // ---- first candidate ----
     float du0, dz0;
@@ -495,11 +494,11 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     // sqrt(du^2 + w^2 + dz^2) rounds to |w| (see lrm_dist_tol_t): q / w^2 above 2^-20 collapses, below 2^-25 stays, between: doubt
     {
         const float q = __builtin_fmaf(du0, du0, dz0 * dz0), w2 = w0 * w0;
-        const bool lv = lim0 && valid0, big = q > w2 * 9.6e-7f, small = q < w2 * 2.9e-8f;
+        const bool lv = lim0 && valid0, big = q > w2 * 9.6e-7f;
         const bool collapse = lv && big;
         du0 = collapse ? 0.f : du0;
         dz0 = collapse ? 0.f : dz0;
-        lu |= (lv && !big && !small) ? LRM_TD_LIMIT : 0u;
+        lu |= (lv && !big) ? LRM_TD_LIMIT : 0u; // (below 2^-25 the reference keeps the vector: one plane point in 1e6, left to the bit-exact code too)
     }
     const float n0 = __builtin_fmaf(du0, du0, __builtin_fmaf(w0, w0, dz0 * dz0));
     const bool flag = valid0 && in0;
@@ -532,16 +531,19 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
 #if !defined(__HIP_DEVICE_COMPILE__)
         lrm_tab_host_seconds++;
 #endif
+        const uint32_t code1 = firstD ? codeF : codeD, cell1 = firstD ? cellF : cellD; // the other candidate's operands: selected here, where they are needed
+        const float w1 = firstD ? wF : wD, x1 = firstD ? xF : xD;
+        const bool lim1 = code1 >= 2u;
         float du1, dz1;
         bool valid1;
         uint32_t bd = 0;
         lrm_tol_plane_tab(G, cell1, x1, z, band, tau, du1, dz1, valid1, bd);
         const float q = __builtin_fmaf(du1, du1, dz1 * dz1), w2 = w1 * w1;
-        const bool lv = lim1 && valid1, big = q > w2 * 9.6e-7f, small = q < w2 * 2.9e-8f;
+        const bool lv = lim1 && valid1, big = q > w2 * 9.6e-7f;
         const bool collapse = lv && big;
         du1 = collapse ? 0.f : du1;
         dz1 = collapse ? 0.f : dz1;
-        bd |= (lv && !big && !small) ? LRM_TD_LIMIT : 0u;
+        bd |= (lv && !big) ? LRM_TD_LIMIT : 0u;
         const float n1 = __builtin_fmaf(du1, du1, __builtin_fmaf(w1, w1, dz1 * dz1));
         // distance_circles' pick (one_leg.cu:334): both invalid here (a valid first candidate never asks for the second): the shorter one
         const float nmin = LRM_FAST_SQRT(fminf(n0, n1));

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised campaign for LRM_MODE_TOL on one GPU: random leg geometries and joint limits around the two reference
-robots, random body orientations, and clouds chosen to be hard -- uniform, the planar bench grid, a cluster around the
-coxa axis, and a cloud pushed ONTO the workspace boundary (every point moved along its own distance vector, then jittered
+robots, random body orientations, and clouds chosen to be hard -- uniform, far (beyond the inner grid of the plane table), near
+and far interleaved, the planar bench grid, a cluster around the coxa axis, and a cloud pushed ONTO the workspace boundary (every point moved along its own distance vector, then jittered
 by 1e-4 .. 1e-1 mm).  The bit-exact mode (LRM_MODE_FAST, itself checked bit for bit against the oracle by the test
 suite) is the reference, on the device: the reach mask and bit words must be identical, the distance field within the
 contract tolerance.  Prints one JSON line; exit code 1 on any violation.
@@ -68,7 +68,14 @@ def main():
                 "uniform": (rng.random((n, 3), dtype=np.float32) * 2 - 1) * np.float32(1.15 * reach),
                 "grid": np.column_stack([rng.uniform(-100, 601, n), np.zeros(n), rng.uniform(-350, 51, n)]).astype(np.float32),
                 "axis": (rng.normal(size=(n, 3)) * np.array([12.0, 12.0, 150.0]) + np.array([leg[1], 0, 0])).astype(np.float32),
+                # beyond the inner grid of the plane table (+-1024 mm of the femur joint): the outer grid and its bound
+                "far": ((rng.random((n, 3), dtype=np.float32) * 2 - 1) * np.float32(1.15 * reach) + np.array([1.6 * reach, 0.8 * reach, 0.0])).astype(np.float32),
             }
+            # near and far points interleaved: every wave takes the outer grid for all its lanes
+            mixed = clouds["uniform"].copy()
+            mixed[::7] = clouds["far"][::7]
+            mixed[3::64] *= np.float32(9.0)  # and a few beyond the outer grid (+-8192 mm) and the table's band limit
+            clouds["mixed"] = mixed
             # around the coxa axis for THIS orientation: points chosen in the coxa frame (radius up to 60 mm from the axis,
             # where the yaw direction amplifies every rounding by target radius / r), mapped back to the body frame:
             # x_coxa = Rp (Rz (Rq^-1 p) - (body, 0, 0)),  Rz = rotation by -body_angle about z, Rp = by -coxa_pitch about y
