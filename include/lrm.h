@@ -58,13 +58,21 @@ extern "C" {
  *                  -use_fast_math CUDA build included; a purely relative bound is unattainable for
  *                  |d| << 10 mm.  The literal bound |d - d_ref| <= 1e-5 |d_ref| holds for every vector of at
  *                  least 16 mm (asserted on the GPU); the fraction of shorter vectors that miss it is reported by
- *                  bench.py ("tolerance_check").  Callers that need the literal text use LRM_MODE_FAST (tolerance 0).
+ *                  bench.py ("tolerance_check").  Callers that need the literal text use LRM_MODE_TOL_REL (below) or LRM_MODE_FAST (tolerance 0).
  *                  Points with any decision inside its error band are re-evaluated by the LRM_MODE_FAST code in a
  *                  second small launch and are bit-identical.  Applies to the distance / fused entry points, host
  *                  buffers (lrm_dist, lrm_reach_dist: the apply_kernel boundary) and device buffers alike;
  *                  reach-only and pair kernels run as in LRM_MODE_FAST.  Legs outside the mode's eligibility use
  *                  LRM_MODE_FAST. */
 #define LRM_MODE_TOL 2
+/* LRM_MODE_TOL_REL: LRM_MODE_TOL with the LITERAL bound of BASELINE.json on every vector: reach mask and validity byte
+ *                  bit-identical, |d - d_ref| <= 1e-5 |d_ref| for every point.  The tolerance kernels queue, next to their
+ *                  doubtful points, every point whose vector comes out shorter than 17 mm; the fix-up launch computes those
+ *                  with the LRM_MODE_FAST code, bit for bit (relative error 0).  Every longer vector is within 1e-5 relative
+ *                  by LRM_MODE_TOL's own arithmetic (measured 7e-6 at most from 16 mm on; asserted: tests/test_gpu_tol.py).
+ *                  About 3 % of a cloud filling the leg's bounding cube is re-evaluated (0.5 % in LRM_MODE_TOL); a cloud that
+ *                  hugs the workspace's surface is re-evaluated whole and runs at LRM_MODE_FAST's speed. */
+#define LRM_MODE_TOL_REL 3
 
 /* LegDimensions, HeaderCPP.h:19-52: 14 x f32 = 56 bytes, this field order. */
 typedef struct LrmLegDimensions {

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LRM_LIB_PATH: load another build of the same library (A/B runs of kernel variants)
 LIB_PATH = os.environ.get("LRM_LIB_PATH") or os.path.join(_HERE, "liblrm.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lrm.h")
-MODE_STRICT, MODE_FAST, MODE_TOL = 0, 1, 2
+MODE_STRICT, MODE_FAST, MODE_TOL, MODE_TOL_REL = 0, 1, 2, 3
 _lib = None
 
 

@@ -26,6 +26,8 @@ namespace {
 thread_local std::string g_err;
 // Process-wide, as documented in lrm.h; atomic so that a helper thread (the host pipeline's) or a second caller thread reads a whole value.
 std::atomic<int> g_mode{LRM_MODE_FAST}; // bit-identical to LRM_MODE_STRICT (tests/test_gpu_parity.py runs both)
+bool tol_mode() { const int m = g_mode; return m == LRM_MODE_TOL || m == LRM_MODE_TOL_REL; }
+uint32_t tol_flags() { return g_mode == LRM_MODE_TOL_REL ? LRM_TOLF_SHORT : 0u; }
 const float kQuatTest[4] = {1.f, 0.f, 0.f, 0.f}; // settings.h:51
 
 int fail(int code, const char* what) {
@@ -146,7 +148,7 @@ int tol_tab_device(TolEntry& E, const uint8_t** out) {
 int launch_dist_mode(int op, const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions& leg,
                      const float* quat, const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                      float* dz, void* stream) {
-    if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xc0000000ull) { // 32-bit point indices in the tolerance kernels (n + one grid stride < 2^32)
+    if (tol_mode() && L.fast_ok && n < 0xc0000000ull) { // 32-bit point indices in the tolerance kernels (n + one grid stride < 2^32)
         TolEntry& E = tol_entry(leg, quat, L);
         const LrmTolLeg& TL = E.tl;
         if (TL.tol_ok) {
@@ -158,8 +160,8 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
             uint32_t* w = nullptr;
             const int rc = tol_workspace(tab ? lrm_tol_tab_queue_words(n) : lrm_tol_queue_words(n), stream, &w);
             if (rc != LRM_OK) return rc;
-            if (tab) HIP_TRY(lrm_launch_dist_tab(op, x, y, z, n, L, TL, tab, mask, bits, dx, dy, dz, w, (hipStream_t)stream), "tolerance-mode (table) launch");
-            else HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, (hipStream_t)stream), "tolerance-mode launch");
+            if (tab) HIP_TRY(lrm_launch_dist_tab(op, x, y, z, n, L, TL, tab, mask, bits, dx, dy, dz, w, tol_flags(), (hipStream_t)stream), "tolerance-mode (table) launch");
+            else HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, tol_flags(), (hipStream_t)stream), "tolerance-mode launch");
             int dev = 0;
             (void)hipGetDevice(&dev);
             // the workspace starts with one count per segment
@@ -177,7 +179,7 @@ int launch_dist_mode(int op, const float* x, const float* y, const float* z, siz
 // distance / fused launch on the float3 arrays of the apply_kernel boundary in the current mode
 int launch_dist_aos_mode(int op, const float* xyz, size_t n, const LrmLegDimensions& leg, const float* quat, const LrmCompiledLeg& L,
                          uint8_t* mask, float* dxyz, void* stream) {
-    if (g_mode == LRM_MODE_TOL && L.fast_ok && n < 0xc0000000ull) {
+    if (tol_mode() && L.fast_ok && n < 0xc0000000ull) {
         TolEntry& E = tol_entry(leg, quat, L);
         const LrmTolLeg& TL = E.tl;
         if (TL.tol_ok) {
@@ -189,8 +191,8 @@ int launch_dist_aos_mode(int op, const float* xyz, size_t n, const LrmLegDimensi
             uint32_t* w = nullptr;
             const int rc = tol_workspace(tab ? lrm_tol_tab_queue_words(n) : lrm_tol_queue_words(n), stream, &w);
             if (rc != LRM_OK) return rc;
-            if (tab) HIP_TRY(lrm_launch_dist_tab_aos(op, xyz, n, L, TL, tab, mask, dxyz, w, (hipStream_t)stream), "tolerance-mode (table) launch");
-            else HIP_TRY(lrm_launch_dist_tol_aos(op, xyz, n, L, TL, mask, dxyz, w, (hipStream_t)stream), "tolerance-mode launch");
+            if (tab) HIP_TRY(lrm_launch_dist_tab_aos(op, xyz, n, L, TL, tab, mask, dxyz, w, tol_flags(), (hipStream_t)stream), "tolerance-mode (table) launch");
+            else HIP_TRY(lrm_launch_dist_tol_aos(op, xyz, n, L, TL, mask, dxyz, w, tol_flags(), (hipStream_t)stream), "tolerance-mode launch");
             return LRM_OK;
         }
     }
@@ -562,7 +564,7 @@ int lrm_set_device(int ordinal) {
     return LRM_OK;
 }
 int lrm_set_mode(int mode) {
-    if (mode != LRM_MODE_STRICT && mode != LRM_MODE_FAST && mode != LRM_MODE_TOL) return fail(LRM_EINVAL, "unknown mode");
+    if (mode != LRM_MODE_STRICT && mode != LRM_MODE_FAST && mode != LRM_MODE_TOL && mode != LRM_MODE_TOL_REL) return fail(LRM_EINVAL, "unknown mode");
     g_mode = mode;
     return LRM_OK;
 }

@@ -20,20 +20,25 @@ hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const flo
 #ifndef LRM_TOL_TAB_SEG_CAP
 #define LRM_TOL_TAB_SEG_CAP 256 // doubt slots per workgroup of the table kernel (1536 points): 17 %
 #endif
+// flags of the tolerance-mode launches (bits 0 and 1 are LRM_TOL_SELFTEST's)
+#define LRM_TOLF_SHORT 4u     // LRM_MODE_TOL_REL: every vector shorter than LRM_TOL_REL_MM is queued for the bit-exact fix-up
+#ifndef LRM_TOL_REL_MM
+#define LRM_TOL_REL_MM 17.0f  // the literal bound |d - d_ref| <= 1e-5 |d_ref| is asserted from 16 mm on; 1 mm for the vector's own error
+#endif
 size_t lrm_tol_queue_words(size_t n);
 hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, uint8_t* mask,
-                                   float* dxyz, uint32_t* workspace, hipStream_t st);
+                                   float* dxyz, uint32_t* workspace, uint32_t flags, hipStream_t st);
 hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz,
-                               uint32_t* workspace, hipStream_t st);
+                               uint32_t* workspace, uint32_t flags, hipStream_t st);
 // Table variant (dist_tab_kernel + the same fix-up): tab_dev = device copy of lrm_build_tol_tab's table for TL.
 size_t lrm_tol_tab_queue_words(size_t n);
 size_t lrm_tol_tab_segments(size_t n); // the workspace starts with one count per segment
 hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
-                               float* dz, uint32_t* workspace, hipStream_t st);
+                               float* dz, uint32_t* workspace, uint32_t flags, hipStream_t st);
 hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const uint8_t* tab_dev,
-                                   uint8_t* mask, float* dxyz, uint32_t* workspace, hipStream_t st);
+                                   uint8_t* mask, float* dxyz, uint32_t* workspace, uint32_t flags, hipStream_t st);
 hipError_t lrm_launch_reach_aos(const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask, bool fast,
                                 hipStream_t st);
 hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask,

@@ -251,6 +251,10 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         uint32_t doubt = lu;
         const bool m = lrm_tol_finish(L, S, A, need, B, p, doubt) && live;
         doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u; // selftest: every point goes to the fix-up
+        if (selftest & LRM_TOLF_SHORT) { // LRM_MODE_TOL_REL (wave-uniform): a vector shorter than LRM_TOL_REL_MM comes from the bit-exact code
+            const float nn = __builtin_fmaf(p.x, p.x, __builtin_fmaf(p.y, p.y, p.z * p.z));
+            doubt |= (live && !(nn >= LRM_TOL_REL_MM * LRM_TOL_REL_MM)) ? 1u : 0u;
+        }
         if (live) {
             if (kAoS) {
                 lrm_at(dx + 3 * rbase, 3u * toff) = p.x;
@@ -318,7 +322,8 @@ struct TabLds {
 constexpr int kTabSegCap = LRM_TOL_TAB_SEG_CAP; // doubt slots per workgroup of dist_tab_kernel
 constexpr int kTabBoundVecs = LRM_TT_NB * LRM_TT_NB * 4 / 16; // 16-byte pieces of the inner grid's bounds
 static_assert(kTabBoundVecs % kBlock == 0, "every thread stages the same number of pieces");
-template <int kOp, bool kAoS = false>
+// kShort: LRM_MODE_TOL_REL (a template argument: as a run-time flag the compiler computes the norm for every point of every mode)
+template <int kOp, bool kAoS = false, bool kShort = false>
 __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
@@ -376,6 +381,10 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
         uint32_t doubt = 0;
         const bool m = lrm_tab_point(L, G, p, doubt) && live;
         doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u; // selftest: every point goes to the fix-up
+        if (kShort) { // LRM_MODE_TOL_REL: a vector shorter than LRM_TOL_REL_MM comes from the bit-exact code
+            const float nn = __builtin_fmaf(p.x, p.x, __builtin_fmaf(p.y, p.y, p.z * p.z));
+            doubt |= (live && !(nn >= LRM_TOL_REL_MM * LRM_TOL_REL_MM)) ? 1u : 0u;
+        }
         if (live) {
             if (kAoS) {
                 lrm_at(dx + 3 * rbase, 3u * toff) = p.x;
@@ -488,16 +497,16 @@ struct FixLds {
 
 // One workgroup: the segments [blockIdx.x * kSegPerWave, +kSegPerWave) of the `nseg` segments (= workgroups) of a main-kernel
 // launch with grid stride `main_stride` points; seg_cap slots per segment.
-template <int kOp, bool kAoS = false, int kSegPerWave = LRM_TOL_SEG_PER_WAVE>
-__global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
+template <int kOp, bool kAoS = false, int kSegPerWave = LRM_TOL_SEG_PER_WAVE, int kThreads = kFixBlock>
+__global__ __launch_bounds__(kThreads) void tol_fixup_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const QueueRec* __restrict__ queue,
     const uint32_t* __restrict__ counts, uint32_t nseg, uint32_t seg_cap, size_t main_stride, uint32_t selftest) {
     __shared__ FixLds s_tab;
     __shared__ uint32_t s_pre[kSegPerWave + 1], s_cnt[kSegPerWave];
-    constexpr uint32_t kQueueAhead = kFixBlock / kSegPerWave;
-    static_assert(kSegPerWave * kQueueAhead <= kFixBlock, "one slot per thread");
+    constexpr uint32_t kQueueAhead = kThreads / kSegPerWave;
+    static_assert(kSegPerWave * kQueueAhead <= kThreads, "one slot per thread");
     __shared__ QueueRec s_q[kSegPerWave][kQueueAhead];
     const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kFixLegArg);
     const uint32_t seg0 = blockIdx.x * kSegPerWave;
@@ -510,9 +519,9 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
         const uint4* src = reinterpret_cast<const uint4*>(&L.lists[0][0]);
         const uint4* dsrc = reinterpret_cast<const uint4*>(&L.dist_tab[0][0]);
         const uint4* csrc = reinterpret_cast<const uint4*>(&L.corner_tab[0]);
-        for (int i = lane; i < (int)(sizeof(s_tab.lists) / 16); i += kFixBlock) reinterpret_cast<uint4*>(s_tab.lists)[i] = src[i];
-        for (int i = lane; i < (int)(sizeof(s_tab.dist) / 16); i += kFixBlock) reinterpret_cast<uint4*>(s_tab.dist)[i] = dsrc[i];
-        for (int i = lane; i < (int)(sizeof(s_tab.corners) / 16); i += kFixBlock) reinterpret_cast<uint4*>(s_tab.corners)[i] = csrc[i];
+        for (int i = lane; i < (int)(sizeof(s_tab.lists) / 16); i += kThreads) reinterpret_cast<uint4*>(s_tab.lists)[i] = src[i];
+        for (int i = lane; i < (int)(sizeof(s_tab.dist) / 16); i += kThreads) reinterpret_cast<uint4*>(s_tab.dist)[i] = dsrc[i];
+        for (int i = lane; i < (int)(sizeof(s_tab.corners) / 16); i += kThreads) reinterpret_cast<uint4*>(s_tab.corners)[i] = csrc[i];
     }
     if (lane < kSegPerWave) s_cnt[lane] = (seg0 + lane < nseg) ? counts[seg0 + lane] : 0u;
     // the first kQueueAhead slots of every segment (usually all that is queued: 2-3 points per segment) come along with the
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
     if (any == 0) return; // nothing in doubt in these workgroups (wave-uniform)
     __syncthreads();
     const LrmDistTables T{s_tab.lists, s_tab.dist, s_tab.corners, (selftest & 2u) ? 1u : 0u};
-    constexpr int kPerPass = kFixBlock / 2; // points per pass of the wave
+    constexpr int kPerPass = kThreads / 2; // points per pass of the wave
     const int slot = lane >> 1, cand = lane & 1;
     // Every lane of the wave comes here in every pass (`live`: this pair has a point): the strict plane evaluations inside
     // are run by the whole wave (lrm_plane_dist_coop).  Both lanes of a pair hold the same point.
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(kFixBlock) void tol_fixup_kernel(
 // LRM_TOL_SELFTEST (tests): bit 0 -- every point is queued (every workgroup's segment overflows: the fix-up re-evaluates the
 // whole cloud, so the outputs must be bit-identical to LRM_MODE_FAST); bit 1 -- every plane evaluation of the fix-up takes
 // the strict path, i.e. the wave-cooperative lrm_plane_dist_coop (still bit-identical).
-static uint32_t tol_selftest() {
+static uint32_t tol_selftest_env() {
     const char* e = getenv("LRM_TOL_SELFTEST");
     return e ? (uint32_t)atoi(e) & 3u : 0u;
 }
@@ -622,19 +631,19 @@ size_t lrm_tol_queue_words(size_t n) { return tol_main_blocks(n) * (4 * kSegCap 
 
 hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz,
-                               uint32_t* workspace /* lrm_tol_queue_words(n) uint32 */, hipStream_t st) {
+                               uint32_t* workspace /* lrm_tol_queue_words(n) uint32 */, uint32_t flags, hipStream_t st) {
     const size_t blocks = tol_main_blocks(n);
     const size_t cap = blocks;
     uint32_t* counts = workspace;
     QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * cap); // 16-byte aligned behind the counts
-    if (op == 2) hipLaunchKernelGGL(dist_tol_staged_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts, tol_selftest());
-    else hipLaunchKernelGGL(dist_tol_staged_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts, tol_selftest());
+    if (op == 2) hipLaunchKernelGGL(dist_tol_staged_kernel<2>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts, flags | tol_selftest_env());
+    else hipLaunchKernelGGL(dist_tol_staged_kernel<1>, dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, queue, counts, flags | tol_selftest_env());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
     const size_t stride = blocks * kBlock;
-    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
-    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
+    if (op == 2) hipLaunchKernelGGL(tol_fixup_kernel<2>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, flags | tol_selftest_env());
+    else hipLaunchKernelGGL(tol_fixup_kernel<1>, dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, flags | tol_selftest_env());
     return hipGetLastError();
 }
 
@@ -642,6 +651,12 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
 // kTabSegCap slots per workgroup.
 #ifndef LRM_TAB_ROUNDS
 #define LRM_TAB_ROUNDS 6 // rounds of a workgroup on large clouds (it stages 17.5 KB of tables once): its doubt segment (kTabSegCap slots) then holds 17 % of its points
+#endif
+#ifndef LRM_TAB_FIX_SEGS_REL
+#define LRM_TAB_FIX_SEGS_REL 8 // LRM_MODE_TOL_REL queues ~3.6 % of a random cloud: ~200 points per fix-up workgroup,
+#endif
+#ifndef LRM_TAB_FIX_BLOCK_REL
+#define LRM_TAB_FIX_BLOCK_REL 256 // of 256 threads: two passes of 128 points
 #endif
 #ifndef LRM_TAB_FIX_SEGS
 #define LRM_TAB_FIX_SEGS 8 // segments per fix-up workgroup: ~60 queued points at the usual 0.5 % of doubt, 1000 workgroups (4 segments, 2000 workgroups: 3 us slower)
@@ -659,45 +674,55 @@ size_t lrm_tol_tab_segments(size_t n) { return tab_main_blocks(n); }
 template <int kOp, bool kAoS>
 static hipError_t launch_tab(const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL,
                              const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace,
-                             hipStream_t st) {
+                             uint32_t flags, hipStream_t st) {
     const size_t blocks = tab_main_blocks(n);
     uint32_t* counts = workspace;
     QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
-    hipLaunchKernelGGL((dist_tab_kernel<kOp, kAoS>), dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts,
-                       tol_selftest());
+    if (flags & LRM_TOLF_SHORT)
+        hipLaunchKernelGGL((dist_tab_kernel<kOp, kAoS, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts,
+                           flags | tol_selftest_env());
+    else
+        hipLaunchKernelGGL((dist_tab_kernel<kOp, kAoS, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts,
+                           flags | tol_selftest_env());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const unsigned fblocks = (unsigned)((blocks + LRM_TAB_FIX_SEGS - 1) / LRM_TAB_FIX_SEGS);
     const size_t stride = blocks * kBlock;
-    hipLaunchKernelGGL((tol_fixup_kernel<kOp, kAoS, LRM_TAB_FIX_SEGS>), dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts,
-                       (uint32_t)blocks, (uint32_t)kTabSegCap, stride, tol_selftest());
+    if (flags & LRM_TOLF_SHORT) { // several times as many queued points: fewer segments per fix-up workgroup keep it at about one pass
+        const unsigned fblocks = (unsigned)((blocks + LRM_TAB_FIX_SEGS_REL - 1) / LRM_TAB_FIX_SEGS_REL);
+        hipLaunchKernelGGL((tol_fixup_kernel<kOp, kAoS, LRM_TAB_FIX_SEGS_REL, LRM_TAB_FIX_BLOCK_REL>), dim3(fblocks), dim3(LRM_TAB_FIX_BLOCK_REL), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts,
+                           (uint32_t)blocks, (uint32_t)kTabSegCap, stride, flags | tol_selftest_env());
+    } else {
+        const unsigned fblocks = (unsigned)((blocks + LRM_TAB_FIX_SEGS - 1) / LRM_TAB_FIX_SEGS);
+        hipLaunchKernelGGL((tol_fixup_kernel<kOp, kAoS, LRM_TAB_FIX_SEGS>), dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts,
+                           (uint32_t)blocks, (uint32_t)kTabSegCap, stride, flags | tol_selftest_env());
+    }
     return hipGetLastError();
 }
 hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
-                               float* dz, uint32_t* workspace /* lrm_tol_tab_queue_words(n) uint32 */, hipStream_t st) {
-    return op == 2 ? launch_tab<2, false>(x, y, z, n, L, TL, tab_dev, mask, bits, dx, dy, dz, workspace, st)
-                   : launch_tab<1, false>(x, y, z, n, L, TL, tab_dev, mask, bits, dx, dy, dz, workspace, st);
+                               float* dz, uint32_t* workspace /* lrm_tol_tab_queue_words(n) uint32 */, uint32_t flags, hipStream_t st) {
+    return op == 2 ? launch_tab<2, false>(x, y, z, n, L, TL, tab_dev, mask, bits, dx, dy, dz, workspace, flags, st)
+                   : launch_tab<1, false>(x, y, z, n, L, TL, tab_dev, mask, bits, dx, dy, dz, workspace, flags, st);
 }
 hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const uint8_t* tab_dev,
-                                   uint8_t* mask, float* dxyz, uint32_t* workspace, hipStream_t st) {
-    return op == 2 ? launch_tab<2, true>(xyz, nullptr, nullptr, n, L, TL, tab_dev, mask, nullptr, dxyz, nullptr, nullptr, workspace, st)
-                   : launch_tab<1, true>(xyz, nullptr, nullptr, n, L, TL, tab_dev, mask, nullptr, dxyz, nullptr, nullptr, workspace, st);
+                                   uint8_t* mask, float* dxyz, uint32_t* workspace, uint32_t flags, hipStream_t st) {
+    return op == 2 ? launch_tab<2, true>(xyz, nullptr, nullptr, n, L, TL, tab_dev, mask, nullptr, dxyz, nullptr, nullptr, workspace, flags, st)
+                   : launch_tab<1, true>(xyz, nullptr, nullptr, n, L, TL, tab_dev, mask, nullptr, dxyz, nullptr, nullptr, workspace, flags, st);
 }
 
 // The same two launches on the float3 arrays of the apply_kernel boundary (cross_compiled.cu:33-79): no bit words.
 hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, uint8_t* mask,
-                                   float* dxyz, uint32_t* workspace /* lrm_tol_queue_words(n) uint32 */, hipStream_t st) {
+                                   float* dxyz, uint32_t* workspace /* lrm_tol_queue_words(n) uint32 */, uint32_t flags, hipStream_t st) {
     const size_t blocks = tol_main_blocks(n);
     uint32_t* counts = workspace;
     QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
-    if (op == 2) hipLaunchKernelGGL((dist_tol_staged_kernel<2, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, tol_selftest());
-    else hipLaunchKernelGGL((dist_tol_staged_kernel<1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, tol_selftest());
+    if (op == 2) hipLaunchKernelGGL((dist_tol_staged_kernel<2, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, flags | tol_selftest_env());
+    else hipLaunchKernelGGL((dist_tol_staged_kernel<1, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, xyz, nullptr, nullptr, n, TL, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, flags | tol_selftest_env());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const unsigned fblocks = (unsigned)((blocks + kSegPerWave - 1) / kSegPerWave);
     const size_t stride = blocks * kBlock;
-    if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
-    else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, tol_selftest());
+    if (op == 2) hipLaunchKernelGGL((tol_fixup_kernel<2, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, flags | tol_selftest_env());
+    else hipLaunchKernelGGL((tol_fixup_kernel<1, true>), dim3(fblocks), dim3(kFixBlock), 0, st, xyz, nullptr, nullptr, n, L, mask, nullptr, dxyz, nullptr, nullptr, queue, counts, (uint32_t)blocks, (uint32_t)kSegCap, stride, flags | tol_selftest_env());
     return hipGetLastError();
 }

@@ -54,7 +54,7 @@ def main():
     field = torch.empty((3, n), dtype=torch.float32, device="cuda")
     bits = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
     out = {"points": n}
-    modes = {"tol": lrm_amd.MODE_TOL, "fast": lrm_amd.MODE_FAST, "strict": lrm_amd.MODE_STRICT}
+    modes = {"tol": lrm_amd.MODE_TOL, "tol_rel": lrm_amd.MODE_TOL_REL, "fast": lrm_amd.MODE_FAST, "strict": lrm_amd.MODE_STRICT}
     for name in args.modes.split(","):
         lrm_amd.set_mode(modes[name])
         fn = lambda: lrm_amd.device.reach_dist(x, y, z, leg, None, mask=mask, out=field, bits=bits)

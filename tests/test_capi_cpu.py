@@ -63,6 +63,7 @@ def test_empty_and_null_arguments(lrm):
     rc = L.lrm_reach_any_dev(None, None, None, 0, None, None, None, 0, None, 0, None, None, None, None)
     assert rc == -1
     assert L.lrm_set_mode(7) == -1
+    assert L.lrm_set_mode(3) == 0 and L.lrm_get_mode() == 3  # LRM_MODE_TOL_REL
     assert L.lrm_set_mode(0) == 0 and L.lrm_get_mode() == 0
     assert L.lrm_set_mode(1) == 0 and L.lrm_get_mode() == 1  # back to the default
 

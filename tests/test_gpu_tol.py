@@ -151,6 +151,38 @@ def test_tol_full_size_config2_1e7_points(lrm, oracle, torch_cuda):
     assert lit[long_enough].max() <= TOL
 
 
+@pytest.mark.parametrize("n,legname,q", [(3_000_000, "m2", None), (300_000, "moonbot", (0.9397, 0, 0, 0.342)), (150_000, "m2", (0.9848, 0, 0.1736, 0))])
+def test_tol_rel_mode_meets_the_literal_contract(lrm, oracle, torch_cuda, n, legname, q):
+    """LRM_MODE_TOL_REL: reach mask bit-exact and |d - d_ref| <= 1e-5 |d_ref| for EVERY vector -- the text of BASELINE.json without a
+    floor.  Vectors that come out shorter than 17 mm are queued and computed by the bit-exact code (bit-identical: relative
+    error 0), every longer one is within 1e-5 relative by the tolerance arithmetic itself.  With the table kernel (3e6, 3e5
+    points) and the staged one (1.5e5)."""
+    pts = random_cloud(n, seed=77)
+    leg = lrm.get_M2_leg(0.3) if legname == "m2" else lrm.get_moonbot_leg(-1.1)
+    x, y, z = soa(torch_cuda, pts)
+    lrm.set_mode(lrm.MODE_TOL_REL)
+    try:
+        bits = torch_cuda.empty((n + 63) // 64, dtype=torch_cuda.int64, device="cuda")
+        m, d, bits = lrm.device.reach_dist(x, y, z, leg, q, mask=torch_cuda.empty(n, dtype=torch_cuda.uint8, device="cuda"), bits=bits)
+        torch_cuda.cuda.synchronize()
+        npts, nq, nover = lrm.dbg_tol_queue_counts()
+    finally:
+        lrm.set_mode(lrm.MODE_TOL)
+    m, d, bits = m.cpu().numpy(), d.cpu().numpy().T, bits.cpu().numpy()
+    oq = (1, 0, 0, 0) if q is None else q
+    want_m = oracle.reach(pts, leg, oq)
+    want_d, want_v = oracle.dist(pts, leg, oq)
+    assert np.array_equal(m, want_m) and np.array_equal(bits.view(np.uint64), packed(want_m))
+    err = np.linalg.norm(d.astype(np.float64) - want_d.astype(np.float64), axis=1)
+    nref = np.linalg.norm(want_d.astype(np.float64), axis=1)
+    assert (err <= TOL * nref).all(), float((err / np.maximum(nref, 1e-300)).max())
+    short = nref < 16.0
+    assert bits_equal(d[short], want_d[short]).all()  # bit for bit, zero vectors (reachable points) included
+    print(f"relative mode, {n} points: max literal relative error {float((err[nref > 0] / nref[nref > 0]).max()):.3e}; "
+          f"{short.mean():.4f} of the vectors < 16 mm; {nq / npts:.4f} of the cloud through the fix-up, {nover} segments overflowed")
+    assert npts == n and nover == 0 and short.mean() <= nq / npts < 0.2
+
+
 def test_tol_queue_overflow_redoes_everything(lrm, oracle, torch_cuda):
     """A cloud in which EVERY point is in doubt (all on the coxa axis neighbourhood): the doubt queue (n/8 slots)
     overflows and the fix-up launch re-evaluates the whole cloud with the bit-exact code."""
@@ -373,14 +405,15 @@ def test_tol_prepare_makes_the_calls_launch_only(lrm, oracle, torch_cuda):
     assert torch.equal(m2, mask) and torch.equal(d2, field)
 
 
-@pytest.mark.parametrize("selftest", ["1", "3"])
-def test_fixup_alone_is_bit_identical_to_the_bit_exact_mode(lrm, torch_cuda, selftest, monkeypatch):
+@pytest.mark.parametrize("selftest,mode", [("1", "tol"), ("3", "tol"), ("3", "tol_rel")])
+def test_fixup_alone_is_bit_identical_to_the_bit_exact_mode(lrm, torch_cuda, selftest, mode, monkeypatch):
     """LRM_TOL_SELFTEST: bit 0 queues EVERY point (all segments overflow, so the fix-up launch re-evaluates the whole cloud
     with the bit-exact code, two lanes per point); bit 1 also sends every plane evaluation of it through the strict path,
     which the fix-up runs wave-cooperatively (lrm_plane_dist_coop: 16 lanes for the clamps and validations, the corner
     points on their own lanes, an ordered minimum for the reference's "first strictly closer").  Either way every output
     bit must equal LRM_MODE_FAST -- masks, bit words, all three floats of every vector, nan patterns included -- for the
-    SoA kernels and for the float3 ones of the apply_kernel boundary."""
+    SoA kernels and for the float3 ones of the apply_kernel boundary.  LRM_MODE_TOL_REL launches the fix-up with workgroups of
+    another size: the same test."""
     torch = torch_cuda
     pts = random_cloud(300_007, seed=123)
     pts[::1001] = np.float32(np.nan)
@@ -394,7 +427,7 @@ def test_fixup_alone_is_bit_identical_to_the_bit_exact_mode(lrm, torch_cuda, sel
         bits0 = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
         m0, d0, bits0 = lrm.device.reach_dist(x, y, z, leg, q, mask=torch.empty(n, dtype=torch.uint8, device="cuda"), bits=bits0)
         a0 = lrm.apply_reach_dist(pts[:70_001], leg, q)
-        lrm.set_mode(lrm.MODE_TOL)
+        lrm.set_mode(lrm.MODE_TOL if mode == "tol" else lrm.MODE_TOL_REL)
         monkeypatch.setenv("LRM_TOL_SELFTEST", selftest)
         for table in ("0", "2"):
             monkeypatch.setenv("LRM_TOL_TABLE", table)
