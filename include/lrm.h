@@ -67,10 +67,11 @@ extern "C" {
 #define LRM_MODE_TOL 2
 /* LRM_MODE_TOL_REL: LRM_MODE_TOL with the LITERAL bound of BASELINE.json on every vector: reach mask and validity byte
  *                  bit-identical, |d - d_ref| <= 1e-5 |d_ref| for every point.  The tolerance kernels queue, next to their
- *                  doubtful points, every point whose vector comes out shorter than 17 mm; the fix-up launch computes those
+ *                  doubtful points, every point whose vector comes out shorter than max(17 mm, 0.03 (|p|_1 + body)) -- the absolute
+ *                  error of the tolerance arithmetic grows with the coordinates --; the fix-up launch computes those
  *                  with the LRM_MODE_FAST code, bit for bit (relative error 0).  Every longer vector is within 1e-5 relative
  *                  by LRM_MODE_TOL's own arithmetic (measured 7e-6 at most from 16 mm on; asserted: tests/test_gpu_tol.py).
- *                  About 3 % of a cloud filling the leg's bounding cube is re-evaluated (0.5 % in LRM_MODE_TOL); a cloud that
+ *                  About 4 % of a cloud filling the leg's bounding cube is re-evaluated (0.5 % in LRM_MODE_TOL); a cloud that
  *                  hugs the workspace's surface is re-evaluated whole and runs at LRM_MODE_FAST's speed. */
 #define LRM_MODE_TOL_REL 3
 

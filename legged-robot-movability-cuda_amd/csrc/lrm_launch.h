@@ -25,6 +25,9 @@ hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const flo
 #ifndef LRM_TOL_REL_MM
 #define LRM_TOL_REL_MM 17.0f  // the literal bound |d - d_ref| <= 1e-5 |d_ref| is asserted from 16 mm on; 1 mm for the vector's own error
 #endif
+#ifndef LRM_TOL_REL_BANDS
+#define LRM_TOL_REL_BANDS 2000.0f // ... and from 2000 decision bands on (30 mm at |p|_1 + body = 1 m): the error grows with the coordinates
+#endif
 size_t lrm_tol_queue_words(size_t n);
 hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, uint8_t* mask,
                                    float* dxyz, uint32_t* workspace, uint32_t flags, hipStream_t st);

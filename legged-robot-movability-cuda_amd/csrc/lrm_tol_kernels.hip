@@ -111,6 +111,14 @@ __device__ __forceinline__ uint32_t lrm_opaque(uint32_t v) {
     return v;
 }
 
+// LRM_MODE_TOL_REL: vectors shorter than this (mm) are computed by the bit-exact code.  The tolerance arithmetic's absolute error
+// grows with the coordinates (~10 ulp of |p|_1 + body: measured <= 0.011 of the decision band on the config-2 cloud and in the
+// campaigns of tools/stress_tol.py --rel); 1e-5 of LRM_TOL_REL_BANDS bands is 0.02 of a band.
+__device__ __forceinline__ float lrm_tol_rel_threshold(const LrmTolLeg& L, const LrmVec3& p) {
+    const float band = __builtin_fmaf(fabsf(p.x) + fabsf(p.y) + fabsf(p.z), L.band_slope, L.band_base);
+    return fmaxf(LRM_TOL_REL_MM, LRM_TOL_REL_BANDS * band);
+}
+
 struct TolLds {
     LrmTolLeg::Circle circ[16];
     LrmCircle feat[LRM_TOL_FEATS];
@@ -192,6 +200,7 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
 #endif
         // ---- A: first candidate ----
         const LrmTolPoint S = lrm_tol_prologue(L, p);
+        const float short_mm = fmaxf(LRM_TOL_REL_MM, LRM_TOL_REL_BANDS * S.band); // LRM_MODE_TOL_REL's threshold (lrm_tol_rel_threshold)
         uint32_t lu = S.lu;
         float du, dzz;
         bool valid;
@@ -251,9 +260,9 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
         uint32_t doubt = lu;
         const bool m = lrm_tol_finish(L, S, A, need, B, p, doubt) && live;
         doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u; // selftest: every point goes to the fix-up
-        if (selftest & LRM_TOLF_SHORT) { // LRM_MODE_TOL_REL (wave-uniform): a vector shorter than LRM_TOL_REL_MM comes from the bit-exact code
+        if (selftest & LRM_TOLF_SHORT) { // LRM_MODE_TOL_REL (wave-uniform): a vector shorter than the threshold comes from the bit-exact code
             const float nn = __builtin_fmaf(p.x, p.x, __builtin_fmaf(p.y, p.y, p.z * p.z));
-            doubt |= (live && !(nn >= LRM_TOL_REL_MM * LRM_TOL_REL_MM)) ? 1u : 0u;
+            doubt |= (live && !(nn >= short_mm * short_mm)) ? 1u : 0u;
         }
         if (live) {
             if (kAoS) {
@@ -379,11 +388,12 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
                                           : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
         }
         uint32_t doubt = 0;
+        const float short_mm = lrm_tol_rel_threshold(L, p); // (of the point, before it becomes the vector)
         const bool m = lrm_tab_point(L, G, p, doubt) && live;
         doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u; // selftest: every point goes to the fix-up
-        if (kShort) { // LRM_MODE_TOL_REL: a vector shorter than LRM_TOL_REL_MM comes from the bit-exact code
+        if (kShort) { // LRM_MODE_TOL_REL: a vector shorter than the threshold comes from the bit-exact code
             const float nn = __builtin_fmaf(p.x, p.x, __builtin_fmaf(p.y, p.y, p.z * p.z));
-            doubt |= (live && !(nn >= LRM_TOL_REL_MM * LRM_TOL_REL_MM)) ? 1u : 0u;
+            doubt |= (live && !(nn >= short_mm * short_mm)) ? 1u : 0u;
         }
         if (live) {
             if (kAoS) {

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--points", type=int, default=400_000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tilt", type=float, default=1.0, help="scale of the random body rotation (1: up to ~40 degrees)")
+    ap.add_argument("--rel", action="store_true",
+                    help="LRM_MODE_TOL_REL instead of LRM_MODE_TOL: the error is the LITERAL relative one, |d - d_ref| / |d_ref| "
+                         "(0 / 0 = 0), against the same 1e-5")
     ap.add_argument("--exact", action="store_true",
                     help="compare LRM_MODE_FAST with LRM_MODE_STRICT instead (the filtered kernels against the plain restatement "
                          "of the reference's arithmetic): every float of the field must be bit-identical")
@@ -101,7 +104,7 @@ def main():
             for name, pts in clouds.items():
                 t = torch.from_numpy(np.ascontiguousarray(pts.T)).cuda()
                 m1, d1, b1 = run(lrm.MODE_STRICT if args.exact else lrm.MODE_FAST, t[0], t[1], t[2], leg, q)
-                m2, d2, b2 = run(lrm.MODE_FAST if args.exact else lrm.MODE_TOL, t[0], t[1], t[2], leg, q)
+                m2, d2, b2 = run(lrm.MODE_FAST if args.exact else (lrm.MODE_TOL_REL if args.rel else lrm.MODE_TOL), t[0], t[1], t[2], leg, q)
                 torch.cuda.synchronize()
                 if not args.exact:
                     try:  # how much of the cloud the tolerance kernel handed to the bit-exact fix-up (doubt bands + unanswered table cells)
@@ -114,6 +117,9 @@ def main():
                 if args.exact:  # "error" = 1 for every point with a differing bit pattern (nan == nan)
                     same = (d1.view(torch.int32) == d2.view(torch.int32)) | (torch.isnan(d1) & torch.isnan(d2))
                     err = (~same.all(dim=0)).to(torch.float32)
+                elif args.rel:
+                    err = torch.nan_to_num((d2 - d1).norm(dim=0) / d1.norm(dim=0), nan=0.0, posinf=float("inf"))  # 0 / 0: equal zero vectors
+                    err = torch.where(torch.isfinite(d1).all(dim=0), err, torch.zeros_like(err))  # non-finite inputs: compared by `nonfinite`
                 else:
                     err = (d2 - d1).norm(dim=0) / torch.maximum(d1.norm(dim=0), (t.norm(dim=0) + float(leg[1])) / 8)
                     err = torch.nan_to_num(err, nan=0.0)  # 0 / 0 at a point on the boundary with a zero vector in both modes
