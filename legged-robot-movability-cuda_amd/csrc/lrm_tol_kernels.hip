@@ -371,12 +371,13 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
 #endif
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t n_pad = (uint32_t)((n + 63) & ~(size_t)63); // whole waves iterate together (ballots below)
+    const uint32_t n32 = (uint32_t)n; // the C ABI sends clouds of 0xc0000000 points and more to the bit-exact kernels: indices fit 32 bits
     QueueRec* seg = queue + (size_t)blockIdx.x * kTabSegCap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t toff0 = threadIdx.x * 4u;
     uint32_t round = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride, round++) {
-        const bool live = i < n;
+        const bool live = i < n32;
         const size_t rbase = (size_t)blockIdx.x * kBlock + (size_t)round * stride;
         const uint32_t toff = lrm_opaque(toff0), tid_o = lrm_opaque(threadIdx.x);
         LrmVec3 p = p_next;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
             const uint32_t i_next = i + stride;
             const size_t rb_next = rbase + stride;
             p_next = LrmVec3{0.f, 0.f, 0.f};
-            if (i_next < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
+            if (i_next < n32) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
                                           : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
         }
         uint32_t doubt = 0;
