@@ -91,9 +91,6 @@
 #endif
 #define LRM_TD_SECOND 0x10000u // statistic only: the second candidate could not be pruned by its lower bound
 
-#ifndef LRM_TAB_FAR_BOUNDS
-#define LRM_TAB_FAR_BOUNDS 0 // 1: the outer grid's bounds come from the table (global memory) instead of the outer circle
-#endif
 #ifndef LRM_TOL_DIET
 #define LRM_TOL_DIET 1
 #endif
@@ -301,25 +298,31 @@ LRM_HD int lrm_dot_bytes(uint32_t a, uint32_t b) {
     return t;
 }
 #endif
-// Look-up of two plane points (x0, z), (x1, z) of one point on grid `far` (0 inner, 1 outer: the same for the whole wave): the codes
-// of their cells, or LRM_TT_UNANSWERED, and the table's lower bounds of their in-plane distances (0 outside the grid).
-// Straight-line code: every lane reads one coarse and one fine entry per plane point, the two coarse loads are issued together,
-// then the two fine loads; the bounds come from G.bound_inner (LDS in the kernel) or, on the outer grid, from the table.
-LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float x0, float x1, float z,
+// Look-up of two plane points (x0, z), (x1, z) of one point: the codes of their cells, or LRM_TT_UNANSWERED, and lower bounds of
+// their in-plane distances (0 outside the grids).  The point uses the outer grid when `far` (its plane points may lie beyond the
+// inner one); `anyfar`: some lane of the wave does (device) / this point does (host).  Straight-line code: every lane reads one
+// coarse and one fine entry per plane point, the two coarse loads are issued together, then the two fine loads; an inner-grid
+// lane takes its bounds from G.bound_inner (LDS in the kernel), an outer-grid lane from the outer circle.
+LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool anyfar, bool far, float x0, float x1, float z,
                                uint32_t& code0, uint32_t& code1, float& lb0, float& lb1) {
-    const float inv = far ? G.inv_h[1] : G.inv_h[0], unit = far ? G.lb_unit[1] : G.lb_unit[0];
-    const uint32_t cbase = far ? G.coarse_off[1] : G.coarse_off[0], fbase = far ? G.fine_off[1] : G.fine_off[0];
     const uint16_t* cells = G.cells;
     // position in units of SUB-cells: q = floor(coordinate / cell size * SUB + OFF * SUB); the cell is q >> 4, the sub-cell q & 15
     // (one FMA, one conversion, one shift and one mask per coordinate).  On the inner grid every plane point lies inside (`far`
-    // is false when max(r + coxa_length, |z|) < far_limit for every lane): positions are positive, truncation is floor, no range
-    // test.  On the outer grid a position is clamped into the grid and the point marked (-> unanswered, bound 0); nan fails the
-    // test too (the conversion maps it to 0).
-    const float invs = inv * (float)LRM_TT_SUB;
+    // is false when max(r + coxa_length, |z|) < far_limit): positions are positive, truncation is floor, no range test.  In a wave
+    // with outer-grid lanes (wave-uniform branch) the grid is chosen per lane, a position is clamped into the grid and the point
+    // marked (-> unanswered, bound 0); nan fails the test too (the conversion maps it to 0).  (Choosing the grid per WAVE sent the
+    // near points of mixed waves to the outer grid's 8 mm sub-cells: three times as many unanswered, i.e. queued, points.)
     constexpr float kOffS = LRM_TT_OFF * (float)LRM_TT_SUB, kMaxS = (float)(LRM_TT_N * LRM_TT_SUB) - 0.5f;
+    float invs = G.inv_h[0] * (float)LRM_TT_SUB;
+    uint32_t cbase = G.coarse_off[0], fbase = G.fine_off[0];
+    if (anyfar) {
+        invs = far ? G.inv_h[1] * (float)LRM_TT_SUB : invs;
+        cbase = far ? G.coarse_off[1] : cbase;
+        fbase = far ? G.fine_off[1] : fbase;
+    }
     float pz = __builtin_fmaf(z, invs, kOffS), p0 = __builtin_fmaf(x0, invs, kOffS), p1 = __builtin_fmaf(x1, invs, kOffS);
     bool out0 = false, out1 = false;
-    if (far) { // wave-uniform
+    if (anyfar) {
         const bool oz = !(pz >= 0.f && pz <= kMaxS);
         out0 = oz || !(p0 >= 0.f && p0 <= kMaxS);
         out1 = oz || !(p1 >= 0.f && p1 <= kMaxS);
@@ -340,36 +343,25 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float x0, float
     const uint32_t b0 = ((c0 & 0x7fffu) << 8) + s0, b1 = ((c1 & 0x7fffu) << 8) + s1; // LRM_TT_SUB^2 = 256 entries per block
     static_assert(LRM_TT_SUB * LRM_TT_SUB == 256, "fine block size");
     const uint32_t f0 = lrm_tt_cell(cells, r0 ? b0 : fbase), f1 = lrm_tt_cell(cells, r1 ? b1 : fbase);
-    const uint32_t k0 = r0 ? f0 : c0, k1 = r1 ? f1 : c1;
-    code0 = k0;
-    code1 = k1;
+    code0 = r0 ? f0 : c0;
+    code1 = r1 ? f1 : c1;
     // The bounds.  Inner grid: one entry per 2 x 2 coarse cells, d0 + unit (gx sx + gz sz) over its 16 x 16 sub-cells, the two
-    // products of signed bytes in one v_dot4 (bytes 2 and 3 of the entry), from LDS.  Outer grid (LRM_TAB_FAR_BOUNDS 0): the
-    // distance beyond the circle that holds every target and every valid point -- far from the workspace that is nearly the
-    // distance itself, and it costs no look-up (the table's outer bounds, read from global memory, made a far cloud 10 % slower
-    // than this: profiles/r03_ab_far_bounds.txt).
+    // products of signed bytes in one v_dot4 (bytes 2 and 3 of the entry), from LDS.  Outer grid: the distance beyond the circle
+    // that holds every target and every valid point -- far from the workspace that is nearly the distance itself, and it costs no
+    // look-up (bounds of the outer grid's cells, read from global memory, made a far cloud 6 % slower: profiles/r03_ab_far_bounds.txt).
     static_assert(LRM_TT_N == 2 * LRM_TT_NB, "bound cell = 2 x 2 coarse cells = 32 sub-cell units");
-    const uint32_t rowb = (qz >> 5) * (uint32_t)LRM_TT_NB;
-    const uint32_t g0 = rowb + (q0 >> 5), g1 = rowb + (q1 >> 5);
+    const uint32_t g0 = (qz >> 5) * (uint32_t)LRM_TT_NB + (q0 >> 5), g1 = (qz >> 5) * (uint32_t)LRM_TT_NB + (q1 >> 5); // (in range for outer-grid lanes too)
     const uint32_t zb = ((qz >> 1) & 15u) << 24;
-    if (far && !LRM_TAB_FAR_BOUNDS) { // wave-uniform
+    const uint32_t e0 = G.bound_inner[g0], e1 = G.bound_inner[g1];
+    const float t0 = (float)lrm_dot_bytes(e0, zb | (((q0 >> 1) & 15u) << 16)), t1 = (float)lrm_dot_bytes(e1, zb | (((q1 >> 1) & 15u) << 16));
+    lb0 = fmaxf(__builtin_fmaf(t0, G.lb_unit[0], lrm_half_bits_to_float(e0)), 0.f);
+    lb1 = fmaxf(__builtin_fmaf(t1, G.lb_unit[0], lrm_half_bits_to_float(e1)), 0.f);
+    if (anyfar) {
         const float zz = z * z;
-        lb0 = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(x0, x0, zz)) - G.r_outer, 0.f);
-        lb1 = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(x1, x1, zz)) - G.r_outer, 0.f);
-    } else {
-        uint32_t e0, e1;
-        if (far) {
-            e0 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * g0);
-            e1 = lrm_tt_cell32(cells, G.bound_off[1] + 2u * g1);
-        } else {
-            e0 = G.bound_inner[g0];
-            e1 = G.bound_inner[g1];
-        }
-        const float t0 = (float)lrm_dot_bytes(e0, zb | (((q0 >> 1) & 15u) << 16)), t1 = (float)lrm_dot_bytes(e1, zb | (((q1 >> 1) & 15u) << 16));
-        lb0 = fmaxf(__builtin_fmaf(t0, unit, lrm_half_bits_to_float(e0)), 0.f);
-        lb1 = fmaxf(__builtin_fmaf(t1, unit, lrm_half_bits_to_float(e1)), 0.f);
-    }
-    if (far) {
+        const float o0 = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(x0, x0, zz)) - G.r_outer, 0.f);
+        const float o1 = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(x1, x1, zz)) - G.r_outer, 0.f);
+        lb0 = far ? o0 : lb0;
+        lb1 = far ? o1 : lb1;
         code0 = out0 ? (uint32_t)LRM_TT_UNANSWERED : code0;
         code1 = out1 ? (uint32_t)LRM_TT_UNANSWERED : code1;
         lb0 = out0 ? 0.f : lb0;
@@ -467,13 +459,14 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     const float ulD = (codeD == 3u) ? um : uM, ulF = (codeF == 3u) ? um : uM;
     const float urD = lrm_u2f(lrm_f2u(r) ^ (codeD << 31)), urF = lrm_u2f(lrm_f2u(r) ^ (codeF << 31));
     const float uD = limD ? ulD : urD, uF = limF ? ulF : urF;
-    // Both plane points lie within max(r + coxa_length, |z|) of the femur joint: one grid for both look-ups -- and for the whole
-    // wave (the outer grid covers the inner one's area too, with coarser cells): the choice lives on the scalar unit.
-    const bool far = LRM_TOL_ANY(!(fmaxf(r + L.coxa_length, fabsf(z)) < G.far_limit));
+    // Both plane points lie within max(r + coxa_length, |z|) of the femur joint: one grid for both look-ups.  A wave without
+    // outer-grid lanes (wave-uniform) skips everything the outer grid needs.
+    const bool far = !(fmaxf(r + L.coxa_length, fabsf(z)) < G.far_limit);
+    const bool anyfar = LRM_TOL_ANY(far);
     const float xD = uD - L.coxa_length, xF = uF - L.coxa_length;
     uint32_t cellD, cellF;
     float lbD, lbF;
-    lrm_toltab_lookup2(G, far, xD, xF, z, cellD, cellF, lbD, lbF);
+    lrm_toltab_lookup2(G, anyfar, far, xD, xF, z, cellD, cellF, lbD, lbF);
     // Which candidate first: the one with the smaller lower bound w^2 + lb^2 of its squared distance (lb: the cell's bound of
     // the in-plane part).  A candidate that may be valid has lb = 0; inside the yaw range (w = 0) its bound is 0 and it goes
     // first -- the reach flag is always taken from the first candidate.  Equal bounds (the two candidates are one

@@ -420,11 +420,11 @@ bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out) {
         hd.lb_unit[g] = (float)(2.0 * Hs[g] / 16.0 / 64.0);
     }
     if (!rows_ok) return false;
-    for (int g = 0; g < 2; g++) { // 32-bit bounds, little endian: d0, then the gradient bytes
+    { // 32-bit bounds of the inner grid, little endian: d0, then the gradient bytes (the outer grid's lanes use the outer circle)
         std::vector<BoundEntry> bounds;
-        build_bounds(grids[g], Hs[g], threads, &bounds);
+        build_bounds(grids[0], Hs[0], threads, &bounds);
         if (cells.size() & 1u) cells.push_back(0);
-        hd.bound_off[g] = (uint32_t)cells.size();
+        hd.bound_off[0] = hd.bound_off[1] = (uint32_t)cells.size();
         for (const BoundEntry& e : bounds) {
             cells.push_back(half_floor(e.d0));
             cells.push_back((uint16_t)(((unsigned)e.gx & 0xffu) | (((unsigned)e.gz & 0xffu) << 8)));

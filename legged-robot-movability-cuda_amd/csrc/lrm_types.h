@@ -172,9 +172,9 @@ struct LrmTolLeg {
 // Lipschitz bounds.  With 16 mm cells refined once to 4 mm, 99.3 % of the plane evaluations of the config-2 cloud
 // are answered (the first-generation table: 92.8 %); the rest go to the bit-exact fix-up like any doubtful point.
 //   layout: LrmTolTabHeader | uint16 cells[]: per grid (inner, outer) coarse[LRM_TT_N^2] and fine[LRM_TT_SUB^2 * max(n_fine, 1)],
-//           then per grid bound[LRM_TT_NB^2] (32 bits each, at an even index)
+//           then the inner grid's bound[LRM_TT_NB^2] (32 bits each, at an even index)
 //   coarse: bit 15 set: refined, bits 0-14 = fine block;  else a cell code
-//   bound:  one entry per BOUND CELL = 2 x 2 coarse cells (32 mm inner, 256 mm outer), {d0 (IEEE half), gx (int8), gz (int8)}:
+//   bound:  one entry per BOUND CELL = 2 x 2 coarse cells (32 mm) of the inner grid, {d0 (IEEE half), gx (int8), gz (int8)}:
 //           max(0, d0 + lb_unit (gx sx + gz sz)) is a LOWER BOUND (mm) of the in-plane part sqrt(du^2 + dz^2) of a yaw candidate's
 //           distance for every plane point of sub-cell (sx, sz), 16 x 16 per bound cell -- 0 wherever a point may be valid.  The
 //           per-point code orders the two yaw candidates by w^2 + bound^2, takes the reach flag from the first and skips the second
@@ -210,7 +210,7 @@ struct LrmTolTabHeader {
     uint32_t coarse_off[2]; // uint16 index, from the end of this header, of each grid's coarse array
     uint32_t fine_off[2];   // ... of each grid's fine blocks (block 0 of a grid without refined cells is a spare)
     float inv_h[2];         // 1 / cell size (mm)
-    uint32_t bound_off[2];  // ... (even) of each grid's array of 32-bit bounds
+    uint32_t bound_off[2];  // ... (even) of the inner grid's array of 32-bit bounds (both entries: the outer grid has none)
     float lb_unit[2];       // the unit of a bound's gradient bytes: (bound cell / 16) / 64 mm
     float band_max;         // the table holds for points whose decision band (mm) is at most this
     float far_limit;        // a point with max(r + coxa_length, |z|) below this has both plane points on the inner grid
