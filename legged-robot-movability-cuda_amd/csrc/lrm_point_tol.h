@@ -250,8 +250,8 @@ struct LrmTolTabView {
     const LrmTabVRow* vrows; // [32]
     const uint16_t* cells;   // the grids' coarse, fine and bound arrays (behind the header)
     const uint32_t* bound_inner; // the inner grid's bounds where the caller keeps them (the kernel: its LDS copy; the host: the table's own)
-    float band_max, far_limit;
-    float inv_h[2], lb_unit[2];
+    float band_max, band_max_outer, far_limit;
+    float inv_h[2], lb_unit;
     uint32_t coarse_off[2], fine_off[2], bound_off[2];
     float r_outer; // every clamp target and every valid point lies within this of the femur joint (LrmTolLeg::r_outer)
 };
@@ -259,7 +259,7 @@ struct LrmTolTabView {
 LRM_HD LrmTolTabView lrm_toltab_view(const uint8_t* tab, const LrmTabRow* rows, const LrmTabVRow* vrows, const uint32_t* bound_inner, float r_outer) {
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
     return LrmTolTabView{rows, vrows, reinterpret_cast<const uint16_t*>(tab + sizeof(LrmTolTabHeader)), bound_inner,
-                         hd->band_max, hd->far_limit, {hd->inv_h[0], hd->inv_h[1]}, {hd->lb_unit[0], hd->lb_unit[1]}, {hd->coarse_off[0], hd->coarse_off[1]},
+                         hd->band_max, hd->band_max_outer, hd->far_limit, {hd->inv_h[0], hd->inv_h[1]}, hd->lb_unit, {hd->coarse_off[0], hd->coarse_off[1]},
                          {hd->fine_off[0], hd->fine_off[1]}, {hd->bound_off[0], hd->bound_off[1]}, r_outer};
 }
 // the table's own copy of the inner grid's bounds (host callers)
@@ -303,8 +303,14 @@ LRM_HD int lrm_dot_bytes(uint32_t a, uint32_t b) {
 // inner one); `anyfar`: some lane of the wave does (device) / this point does (host).  Straight-line code: every lane reads one
 // coarse and one fine entry per plane point, the two coarse loads are issued together, then the two fine loads; an inner-grid
 // lane takes its bounds from G.bound_inner (LDS in the kernel), an outer-grid lane from the outer circle.
-LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool anyfar, bool far, float x0, float x1, float z,
-                               uint32_t& code0, uint32_t& code1, float& lb0, float& lb1) {
+// kMixed: the variant for a wave with outer-grid lanes (two instances: written as ONE body with `if (anyfar)` blocks the compiler turns
+// the blocks into selects that every wave executes -- 6 instructions per point).  band_doubt: the point's decision band exceeds what its
+// grid was built for.
+template <bool kMixed>
+LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float band, float x0, float x1, float z,
+                               uint32_t& code0, uint32_t& code1, float& lb0, float& lb1, bool& band_doubt) {
+    constexpr bool anyfar = kMixed;
+    if (!kMixed) far = false;
     const uint16_t* cells = G.cells;
     // position in units of SUB-cells: q = floor(coordinate / cell size * SUB + OFF * SUB); the cell is q >> 4, the sub-cell q & 15
     // (one FMA, one conversion, one shift and one mask per coordinate).  On the inner grid every plane point lies inside (`far`
@@ -322,7 +328,9 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool anyfar, bool far, fl
     }
     float pz = __builtin_fmaf(z, invs, kOffS), p0 = __builtin_fmaf(x0, invs, kOffS), p1 = __builtin_fmaf(x1, invs, kOffS);
     bool out0 = false, out1 = false;
+    band_doubt = !(band <= G.band_max);
     if (anyfar) {
+        band_doubt = !(band <= (far ? G.band_max_outer : G.band_max));
         const bool oz = !(pz >= 0.f && pz <= kMaxS);
         out0 = oz || !(p0 >= 0.f && p0 <= kMaxS);
         out1 = oz || !(p1 >= 0.f && p1 <= kMaxS);
@@ -354,8 +362,8 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool anyfar, bool far, fl
     const uint32_t zb = ((qz >> 1) & 15u) << 24;
     const uint32_t e0 = G.bound_inner[g0], e1 = G.bound_inner[g1];
     const float t0 = (float)lrm_dot_bytes(e0, zb | (((q0 >> 1) & 15u) << 16)), t1 = (float)lrm_dot_bytes(e1, zb | (((q1 >> 1) & 15u) << 16));
-    lb0 = fmaxf(__builtin_fmaf(t0, G.lb_unit[0], lrm_half_bits_to_float(e0)), 0.f);
-    lb1 = fmaxf(__builtin_fmaf(t1, G.lb_unit[0], lrm_half_bits_to_float(e1)), 0.f);
+    lb0 = fmaxf(__builtin_fmaf(t0, G.lb_unit, lrm_half_bits_to_float(e0)), 0.f);
+    lb1 = fmaxf(__builtin_fmaf(t1, G.lb_unit, lrm_half_bits_to_float(e1)), 0.f);
     if (anyfar) {
         const float zz = z * z;
         const float o0 = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(x0, x0, zz)) - G.r_outer, 0.f);
@@ -449,7 +457,7 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     const uint32_t codeD = (kLutD >> (pat << 1)) & 3u, codeF = (kLutF >> (pat << 1)) & 3u;
     const bool inD = (pat & 5u) == 1u, inF = (pat & 5u) == 4u;
     const float ymin = lrm_min3_aa(wm, um, lrm_min3_aa(wM, uM, 3.0e38f));
-    uint32_t lu = (!(ymin > band) || !(r > LRM_TOL_RMIN) || !(band <= G.band_max)) ? LRM_TD_YAW : 0u;
+    uint32_t lu = (!(ymin > band) || !(r > LRM_TOL_RMIN)) ? LRM_TD_YAW : 0u;
     const bool two = codeD != codeF;
     // plane point of a candidate kind: abscissa {r, -r, uM, um}[code], offset {0, 0, wM, wm}[code].  Every `?:` below
     // selects between values that exist already: straight-line v_cndmask code, no branches.
@@ -466,7 +474,10 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     const float xD = uD - L.coxa_length, xF = uF - L.coxa_length;
     uint32_t cellD, cellF;
     float lbD, lbF;
-    lrm_toltab_lookup2(G, anyfar, far, xD, xF, z, cellD, cellF, lbD, lbF);
+    bool band_doubt;
+    if (anyfar) lrm_toltab_lookup2<true>(G, far, band, xD, xF, z, cellD, cellF, lbD, lbF, band_doubt);
+    else lrm_toltab_lookup2<false>(G, false, band, xD, xF, z, cellD, cellF, lbD, lbF, band_doubt);
+    lu |= band_doubt ? LRM_TD_YAW : 0u;
     // Which candidate first: the one with the smaller lower bound w^2 + lb^2 of its squared distance (lb: the cell's bound of
     // the in-plane part).  A candidate that may be valid has lb = 0; inside the yaw range (w = 0) its bound is 0 and it goes
     // first -- the reach flag is always taken from the first candidate.  Equal bounds (the two candidates are one

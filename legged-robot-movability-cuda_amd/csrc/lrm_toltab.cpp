@@ -375,16 +375,16 @@ uint16_t half_floor(double v) {
 
 // -> false when the leg needs more distinct rows than a cell code can name (the caller then uses the kernels without a table)
 bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out) {
-    // the largest decision band the table is built for: points up to |p|_1 = 4096 mm
-    const double band = (double)L.band_base + (double)L.band_slope * 4096.0;
-    const double tau = band * (double)LRM_TOL_TIE;
+    // the largest decision bands the grids are built for: points up to |p|_1 = 4096 mm on the inner grid (whatever lies further
+    // out is beyond it), 16384 mm on the outer one (its cells are 8 times as large: the band stays the same fraction of a sub-cell)
+    const double bands[2] = {(double)L.band_base + (double)L.band_slope * 4096.0, (double)L.band_base + (double)L.band_slope * 16384.0};
     constexpr int N = LRM_TT_N, kSub = LRM_TT_SUB;
     int threads = (int)std::thread::hardware_concurrency();
     threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads);
     if (const char* e = std::getenv("LRM_TOLTAB_THREADS")) threads = std::max(1, std::atoi(e));
     const double Hs[2] = {LRM_TT_H_INNER, LRM_TT_H_OUTER};
     GridCells grids[2];
-    for (int g = 0; g < 2; g++) classify_grid(L, Hs[g], band, tau, threads, &grids[g]);
+    for (int g = 0; g < 2; g++) classify_grid(L, Hs[g], bands[g], bands[g] * (double)LRM_TOL_TIE, threads, &grids[g]);
     Rows R;
     R.row(kNoneRow);   // row 0
     R.vrow(kFalseRow); // validity rows 0, 1
@@ -417,7 +417,7 @@ bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out) {
             for (const CellCode& c : blk) cells.push_back(code_of(c));
         if (G.fine.empty()) cells.insert(cells.end(), (size_t)kSub * kSub, (uint16_t)LRM_TT_UNANSWERED); // the lookup reads block 0 for unrefined cells
         hd.inv_h[g] = (float)(1.0 / Hs[g]);
-        hd.lb_unit[g] = (float)(2.0 * Hs[g] / 16.0 / 64.0);
+        if (g == 0) hd.lb_unit = (float)(2.0 * Hs[g] / 16.0 / 64.0);
     }
     if (!rows_ok) return false;
     { // 32-bit bounds of the inner grid, little endian: d0, then the gradient bytes (the outer grid's lanes use the outer circle)
@@ -430,7 +430,8 @@ bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out) {
             cells.push_back((uint16_t)(((unsigned)e.gx & 0xffu) | (((unsigned)e.gz & 0xffu) << 8)));
         }
     }
-    hd.band_max = (float)band;
+    hd.band_max = (float)bands[0];
+    hd.band_max_outer = (float)bands[1];
     // both plane points of a point lie within max(r + coxa_length, |z|) of the femur joint (|u| <= r)
     hd.far_limit = (float)(0.5 * N * Hs[0] - 1.0);
     hd.n_rows = (uint32_t)R.rows.size();

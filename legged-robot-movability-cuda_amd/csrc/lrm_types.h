@@ -211,8 +211,9 @@ struct LrmTolTabHeader {
     uint32_t fine_off[2];   // ... of each grid's fine blocks (block 0 of a grid without refined cells is a spare)
     float inv_h[2];         // 1 / cell size (mm)
     uint32_t bound_off[2];  // ... (even) of the inner grid's array of 32-bit bounds (both entries: the outer grid has none)
-    float lb_unit[2];       // the unit of a bound's gradient bytes: (bound cell / 16) / 64 mm
-    float band_max;         // the table holds for points whose decision band (mm) is at most this
+    float lb_unit;          // the unit of a bound's gradient bytes: (bound cell / 16) / 64 mm
+    float band_max_outer;   // the outer grid holds for points whose decision band (mm) is at most this (|p|_1 <= 16384 mm)
+    float band_max;         // the inner grid: ... at most this (|p|_1 <= 4096 mm)
     float far_limit;        // a point with max(r + coxa_length, |z|) below this has both plane points on the inner grid
     uint32_t n_rows, n_vrows;
     LrmTabRow rows[32];

@@ -235,13 +235,15 @@ def test_tol_with_and_without_the_plane_table(lrm, oracle, torch_cuda, table, mo
             check_outputs(pts, m.cpu().numpy(), None, d.cpu().numpy().T, bits.cpu().numpy(), oracle.reach(pts, leg, q), want_v, want_d, leg)
 
 
-def test_tol_far_cloud_uses_the_outer_grid(lrm, oracle, torch_cuda):
+@pytest.mark.parametrize("shift", [900.0, 3000.0, 6000.0])
+def test_tol_far_cloud_uses_the_outer_grid(lrm, oracle, torch_cuda, shift):
     """points beyond +-1024 mm of the femur joint (the inner grid's range) are answered by the outer grid, not by the
-    fix-up: the queue stays a few per cent and the results stay in tolerance"""
+    fix-up: the queue stays a few per cent and the results stay in tolerance -- out to the outer grid's own range (+-8 m: it is
+    built for the decision bands of points up to |p|_1 = 16 m)"""
     n = 500_000
     pts = random_cloud(n, seed=33)
-    pts[:, 0] += 900.0
-    pts[::7, 1] *= 6.0  # some as far as 3 m out
+    pts[:, 0] += np.float32(shift)
+    pts[::7, 1] *= 6.0  # some as far as 3 m out sideways
     leg = lrm.get_M2_leg(0.5)
     x, y, z = soa(torch_cuda, pts)
     m, d = lrm.device.reach_dist(x, y, z, leg, None)

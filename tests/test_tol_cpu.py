@@ -68,13 +68,14 @@ def test_tol_nonfinite_inputs_are_in_doubt(lrm):
 
 
 @pytest.mark.parametrize("legname,az,q", [("m2", 0.0, QUATS[0]), ("moonbot", np.pi / 3, QUATS[1]), ("m2", -2.0, QUATS[3])])
-@pytest.mark.parametrize("shift", [0.0, 900.0])
+@pytest.mark.parametrize("shift", [0.0, 900.0, 4000.0])
 def test_tol_plane_table_vs_oracle(lrm, oracle, legname, az, q, shift):
     """The plane table with deferred decisions (csrc/lrm_toltab.cpp) replaces the full plane evaluation: a cell names at
     most two clamp targets and one open validity, everything else is decided per cell on the host.  Every point the
     table path resolves (no doubt bit, no 0x100 "unanswered cell") must carry the oracle's mask and a vector inside the
     tolerance; unanswered points (sent to the bit-exact fix-up on the GPU) must stay a small fraction -- on the inner
-    grid (the config-2 cube) and on the outer one (the cube shifted beyond +-1024 mm of the femur joint)."""
+    grid (the config-2 cube) and on the outer one (the cube shifted beyond +-1024 mm of the femur joint, and 4 m out: the outer grid is
+    built for the larger decision bands of far points)."""
     leg = lrm.get_M2_leg(az) if legname == "m2" else lrm.get_moonbot_leg(az)
     pts = random_cloud(200_000, seed=17)
     pts[:, 0] += np.float32(shift)
@@ -85,13 +86,13 @@ def test_tol_plane_table_vs_oracle(lrm, oracle, legname, az, q, shift):
     e = field_error(pts[sure], d[sure], want_d[sure], leg)
     assert e["metric"].max(initial=0.0) <= TOL
     assert 4 <= stats["rows"] <= 31 and 2 <= stats["vrows"] <= 31 and stats["refined"] > 0 and stats["bytes"] < 2_000_000
-    assert ((doubt & 0x100) != 0).mean() < 0.02
-    assert sure.mean() > 0.97
+    assert ((doubt & 0x100) != 0).mean() < (0.02 if shift < 2000 else 0.05)
+    assert sure.mean() > (0.97 if shift < 2000 else 0.95)
     # same decisions as the full evaluation wherever both are certain (the arithmetic differs in the last bits only)
     m2, d2, doubt2 = lrm.dbg_tol_host(pts, leg, q)
     both = sure & ((doubt2 & 0xffff) == 0)
     assert np.array_equal(m[both], m2[both])
-    assert np.abs(d[both] - d2[both]).max() < 1e-3
+    assert (np.abs(d[both] - d2[both]) <= 1e-3 + 1e-6 * np.abs(d2[both])).all()  # (a few ulp of the vector where it is metres long)
 
 
 @pytest.mark.parametrize("legname,az,q", [("m2", 0.0, QUATS[0]), ("moonbot", np.pi / 3, QUATS[1]), ("m2", -2.0, QUATS[3])])
