@@ -73,6 +73,8 @@ def main():
                 "axis": (rng.normal(size=(n, 3)) * np.array([12.0, 12.0, 150.0]) + np.array([leg[1], 0, 0])).astype(np.float32),
                 # beyond the inner grid of the plane table (+-1024 mm of the femur joint): the outer grid and its bound
                 "far": ((rng.random((n, 3), dtype=np.float32) * 2 - 1) * np.float32(1.15 * reach) + np.array([1.6 * reach, 0.8 * reach, 0.0])).astype(np.float32),
+                # several metres out: the outer grid's own decision band
+                "far3": ((rng.random((n, 3), dtype=np.float32) * 2 - 1) * np.float32(1.5 * reach) + np.array([5.0 * reach, 2.0 * reach, reach])).astype(np.float32),
             }
             # near and far points interleaved: every wave takes the outer grid for all its lanes
             mixed = clouds["uniform"].copy()
