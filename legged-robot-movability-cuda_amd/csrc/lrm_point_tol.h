@@ -252,7 +252,7 @@ struct LrmTolTabView {
     const uint32_t* bound_inner; // the inner grid's bounds where the caller keeps them (the kernel: its LDS copy; the host: the table's own)
     float band_max, band_max_outer, far_limit;
     float inv_h[2], lb_unit;
-    uint32_t coarse_off[2], fine_off[2], bound_off[2];
+    uint32_t coarse_off[2], fine_off[2];
     float r_outer; // every clamp target and every valid point lies within this of the femur joint (LrmTolLeg::r_outer)
 };
 // rows / vrows / bound_inner: where the caller keeps them (the kernel: its LDS copies; the host: the table's own)
@@ -260,7 +260,7 @@ LRM_HD LrmTolTabView lrm_toltab_view(const uint8_t* tab, const LrmTabRow* rows, 
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
     return LrmTolTabView{rows, vrows, reinterpret_cast<const uint16_t*>(tab + sizeof(LrmTolTabHeader)), bound_inner,
                          hd->band_max, hd->band_max_outer, hd->far_limit, {hd->inv_h[0], hd->inv_h[1]}, hd->lb_unit, {hd->coarse_off[0], hd->coarse_off[1]},
-                         {hd->fine_off[0], hd->fine_off[1]}, {hd->bound_off[0], hd->bound_off[1]}, r_outer};
+                         {hd->fine_off[0], hd->fine_off[1]}, r_outer};
 }
 // the table's own copy of the inner grid's bounds (host callers)
 inline const uint32_t* lrm_toltab_bound_inner(const uint8_t* tab) {
@@ -277,17 +277,12 @@ LRM_HD uint32_t lrm_tt_cell(const uint16_t* cells, uint32_t i) {
 #endif
     return *(const __attribute__((address_space(1))) uint16_t*)((GP)cells + (i << 1));
 }
-LRM_HD uint32_t lrm_tt_cell32(const uint16_t* cells, uint32_t i) { // the 32-bit word that starts at cells[i], i even
-    typedef const __attribute__((address_space(1))) char* GP;
-    return *(const __attribute__((address_space(1))) uint32_t*)((GP)cells + (i << 1));
-}
 LRM_HD float lrm_half_bits_to_float(uint32_t h) { // the low 16 bits (v_cvt_f32_f16 reads nothing else)
     return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
 }
 LRM_HD int lrm_dot_bytes(uint32_t a, uint32_t b) { return __builtin_amdgcn_sdot4((int)a, (int)b, 0, false); } // sum of the four products of signed bytes
 #else
 LRM_HD uint32_t lrm_tt_cell(const uint16_t* cells, uint32_t i) { return cells[i]; }
-LRM_HD uint32_t lrm_tt_cell32(const uint16_t* cells, uint32_t i) { return (uint32_t)cells[i] | ((uint32_t)cells[i + 1] << 16); }
 LRM_HD float lrm_half_bits_to_float(uint32_t h) { // normal halves and zero only (lrm_toltab.cpp writes nothing else)
     const uint32_t e = (h >> 10) & 31u, f = h & 1023u;
     return e == 0u ? 0.f : lrm_u2f(((h & 0x8000u) << 16) | ((e + 112u) << 23) | (f << 13));
