@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--reps", type=int, default=300)
     ap.add_argument("--modes", default="tol,fast,strict")
+    ap.add_argument("--leg", default="m2", choices=["m2", "moonbot"])
+    ap.add_argument("--azimut", type=float, default=0.0, help="body angle of the leg (rad)")
     ap.add_argument("--cloud", default="cube", choices=["cube", "grid", "reachable", "far"],
                     help="cube: config 2 (uniform in the leg's bounding cube); grid: the reference's planar bench grid (y = 0), random samples of it; reachable / far: only reachable points (resampled from the cube) / only points beyond the workspace: the two ends of the lane divergence")
     args = ap.parse_args()
@@ -49,7 +51,7 @@ def main():
             have += keep.shape[1]
         cloud = torch.cat(parts, dim=1)[:, :n].contiguous()
     x, y, z = cloud[0], cloud[1], cloud[2]
-    leg = lrm_amd.get_M2_leg(0.0)
+    leg = lrm_amd.get_M2_leg(args.azimut) if args.leg == "m2" else lrm_amd.get_moonbot_leg(args.azimut)
     mask = torch.empty(n, dtype=torch.uint8, device="cuda")
     field = torch.empty((3, n), dtype=torch.float32, device="cuda")
     bits = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
