@@ -8,7 +8,7 @@
 // 3 repeats, rbdl.csv) runs the RBDL-equivalent Levenberg-Marquardt IK of lrm_rbdl_equiv_cpu: RBDL itself is
 // an external, unpinned dependency that is absent here -- a timing baseline, parity unpinned.
 //
-//   lrm_bench [outdir] [min_pix] [gpu_repeats] [cpu_repeats] [rbdl_repeats] [min_pix_rbdl] [fast|tol|strict]
+//   lrm_bench [outdir] [min_pix] [gpu_repeats] [cpu_repeats] [rbdl_repeats] [min_pix_rbdl] [fast|tol|tol_rel|strict]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,9 +48,9 @@ int main(int argc, char** argv) {
     const int cpu_rep = argc > 4 ? atoi(argv[4]) : 10;             // SubSamples_CPU
     const int rbdl_rep = argc > 5 ? atoi(argv[5]) : 3;             // SubSamples_RBDL
     const float min_pix_rbdl = argc > 6 ? (float)atof(argv[6]) : 0.4f; // MinPixRBDL
-    if (argc > 7) { // arithmetic mode of the GPU kernels: fast (default, bit-exact) | tol (contract tolerance) | strict
+    if (argc > 7) { // arithmetic mode of the GPU kernels: fast (default, bit-exact) | tol (contract tolerance) | tol_rel (1e-5 relative on every vector) | strict
         const std::string m = argv[7];
-        const int mode = m == "tol" ? LRM_MODE_TOL : (m == "strict" ? LRM_MODE_STRICT : LRM_MODE_FAST);
+        const int mode = m == "tol" ? LRM_MODE_TOL : (m == "tol_rel" ? LRM_MODE_TOL_REL : (m == "strict" ? LRM_MODE_STRICT : LRM_MODE_FAST));
         if (lrm_set_mode(mode) != 0) {
             std::cerr << "lrm_set_mode failed" << std::endl;
             return 1;
