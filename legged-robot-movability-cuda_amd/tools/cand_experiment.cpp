@@ -121,6 +121,7 @@ int main(int argc, char** argv) {
     std::mt19937_64 rng(42);
     std::uniform_real_distribution<float> U(0.f, 1.f);
     size_t two = 0, need = 0, flag = 0, cls[2][2] = {{0}}, wins1[2][2] = {{0}}, need_new[2][2] = {{0}}, wrong = 0;
+    size_t close_gap[4] = {0, 0, 0, 0}; // | |d_1| - |d_0| | below 4 / 16 / 32 / 64 mm
     for (size_t i = 0; i < n; i++) {
         LrmVec3 p{U(rng) * 900.f - 200.f, U(rng) * 1000.f - 500.f, U(rng) * 800.f - 500.f};
         const LrmTolPoint S = lrm_tol_prologue(L, p);
@@ -137,6 +138,10 @@ int main(int argc, char** argv) {
         const LrmTolCand B = lrm_tol_candidate(S, true, du, dz, valid, lu);
         cls[S.lim0][S.lim1]++;
         if (B.n < A.n) wins1[S.lim0][S.lim1]++;
+        {
+            const double gap = std::fabs(std::sqrt((double)B.n) - std::sqrt((double)A.n));
+            close_gap[0] += gap < 4.0; close_gap[1] += gap < 16.0; close_gap[2] += gap < 32.0; close_gap[3] += gap < 64.0;
+        }
         // the new scheme: bounds b_i = w_i^2 + lb_i^2; the candidate in range goes first, else the smaller bound; the other one is
         // needed unless n_first < b_other - thr
         float lb0 = lb_at(S.u0, S.z), lb1 = lb_at(S.u1, S.z);
@@ -149,6 +154,8 @@ int main(int argc, char** argv) {
         if (!(nf < bo - thr)) need_new[S.lim0][S.lim1]++;
     }
     printf("H %.0f mm, points %zu: flag %.4f, two&&!flag %.4f, need (present bound) %.4f; bound violated %zu\n", H, n, (double)flag / n, (double)two / n, (double)need / n, wrong);
+    printf("  the two candidates differ by less than 4 / 16 / 32 / 64 mm for %.4f / %.4f / %.4f / %.4f of the points\n", (double)close_gap[0] / n,
+           (double)close_gap[1] / n, (double)close_gap[2] / n, (double)close_gap[3] / n);
     size_t tot = 0;
     for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) if (cls[a][b]) {
         printf("  first clamped %d second clamped %d: %.4f of points; second wins %.4f; need with cell bounds %.5f\n", a, b, (double)cls[a][b] / n, (double)wins1[a][b] / n, (double)need_new[a][b] / n);

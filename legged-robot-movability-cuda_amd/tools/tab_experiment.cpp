@@ -18,7 +18,6 @@ int main(int argc, char** argv) {
     const double band = (double)L.band_base + (double)L.band_slope * 4096.0, tau = band * LRM_TOL_TIE;
     for (double h : {16.0, 4.0, 1.0}) {
         std::unordered_map<uint64_t, int> memo; // cell -> reason (0 = answered)
-        Rows R;
         size_t cnt[8] = {0}, lookups = 0, defer = 0;
         std::mt19937_64 rng(42);
         std::uniform_real_distribution<float> U(0.f, 1.f);
@@ -37,9 +36,10 @@ int main(int argc, char** argv) {
                 auto it = memo.find(key);
                 if (it == memo.end()) {
                     g_reason = 0;
-                    const unsigned c = classify_cell(L, R, (ix + 0.5) * h, (iz + 0.5) * h, 0.5 * h * 1.41421357, band, tau);
-                    int r = c == LRM_TT_UNANSWERED ? g_reason : 0;
-                    if (c != LRM_TT_UNANSWERED && (((c >> 5) & 31u) != 0u || (c >> 10) > 1u)) r = -1;
+                    const CellCode c = classify_cell(L, (ix + 0.5) * h, (iz + 0.5) * h, 0.5 * h * 1.41421357, band, tau);
+                    int r = c.ok ? 0 : g_reason;
+                    const bool open_validity = std::memcmp(&c.v, &kFalseRow, sizeof c.v) != 0 && std::memcmp(&c.v, &kTrueRow, sizeof c.v) != 0;
+                    if (c.ok && (c.n == 2 || open_validity)) r = -1; // a cell that defers a decision to the lane
                     it = memo.emplace(key, r).first;
                 }
                 lookups++;
