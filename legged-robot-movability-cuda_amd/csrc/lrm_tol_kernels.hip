@@ -389,6 +389,7 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
                                           : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
         }
         uint32_t doubt = 0;
+        const LrmVec3 p_in = p; // kept for the queue record (three registers; re-loading it cost a pushing wave an L2 round trip)
         const float short_mm = lrm_tol_rel_threshold(L, p); // (of the point, before it becomes the vector)
         const bool m = lrm_tab_point(L, G, p, doubt) && live;
         doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u; // selftest: every point goes to the fix-up
@@ -419,11 +420,7 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
             if (doubt) {
                 const uint32_t qs = qb + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
-                if (qs < (uint32_t)kTabSegCap) { // beyond: the count tells the fix-up to redo the workgroup.  The point comes back from the L2 (loaded a round ago)
-                    const LrmVec3 q = kAoS ? LrmVec3{lrm_at(x + 3 * rbase, 3u * toff), lrm_at(x + 3 * rbase, 3u * toff + 4u), lrm_at(x + 3 * rbase, 3u * toff + 8u)}
-                                           : LrmVec3{lrm_at(x + rbase, toff), lrm_at(y + rbase, toff), lrm_at(z + rbase, toff)};
-                    seg[qs] = QueueRec{i, q.x, q.y, q.z};
-                }
+                if (qs < (uint32_t)kTabSegCap) seg[qs] = QueueRec{i, p_in.x, p_in.y, p_in.z}; // beyond: the count tells the fix-up to redo the workgroup
             }
         }
     }
