@@ -1056,7 +1056,7 @@ int lrm_dbg_toltab_bounds(const float* xz, size_t n, const LrmLegDimensions* leg
         const int g = (std::fabs(x) < G.far_limit && std::fabs(z) < G.far_limit) ? 0 : 1;
         uint32_t c0, c1;
         float l0, l1;
-        { bool bd; if (g) lrm_toltab_lookup2<true>(G, true, 0.f, x, x, z, c0, c1, l0, l1, bd); else lrm_toltab_lookup2<false>(G, false, 0.f, x, x, z, c0, c1, l0, l1, bd); }
+        { bool bd; uint32_t s0, s1, fb; if (g) lrm_toltab_lookup2<true>(G, true, 0.f, x, x, z, c0, c1, s0, s1, fb, l0, l1, bd); else lrm_toltab_lookup2<false>(G, false, 0.f, x, x, z, c0, c1, s0, s1, fb, l0, l1, bd); }
         lb_out[i] = l0;
         const float band = TL.band_base + TL.band_slope * (std::fabs(x) + std::fabs(z)), tau = band * LRM_TOL_TIE;
         float du, dz;

@@ -303,7 +303,7 @@ LRM_HD int lrm_dot_bytes(uint32_t a, uint32_t b) {
 // grid was built for.
 template <bool kMixed>
 LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float band, float x0, float x1, float z,
-                               uint32_t& code0, uint32_t& code1, float& lb0, float& lb1, bool& band_doubt) {
+                               uint32_t& c0, uint32_t& c1, uint32_t& s0, uint32_t& s1, uint32_t& fbase_out, float& lb0, float& lb1, bool& band_doubt) {
     constexpr bool anyfar = kMixed;
     if (!kMixed) far = false;
     const uint16_t* cells = G.cells;
@@ -337,17 +337,14 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float band, flo
     static_assert(LRM_TT_SUB == 16, "shifts below");
     const uint32_t row = (qz >> 4) * (uint32_t)LRM_TT_N;
     const uint32_t a0 = row + (q0 >> 4), a1 = row + (q1 >> 4); // cell numbers
-    const uint32_t c0 = lrm_tt_cell(cells, cbase + a0), c1 = lrm_tt_cell(cells, cbase + a1);
-    // sub-cell inside a refined cell
+    c0 = lrm_tt_cell(cells, cbase + a0);
+    c1 = lrm_tt_cell(cells, cbase + a1);
+    // where the sub-cell sits inside a refined cell's block: the caller resolves (lrm_toltab_resolve) only the candidate it evaluates
     const uint32_t szn = qz & 15u, sx0 = q0 & 15u, sx1 = q1 & 15u;
     const uint32_t sz = szn * (uint32_t)LRM_TT_SUB + fbase;
-    const uint32_t s0 = sz + sx0, s1 = sz + sx1;
-    const bool r0 = (c0 & 0x8000u) != 0u, r1 = (c1 & 0x8000u) != 0u;
-    const uint32_t b0 = ((c0 & 0x7fffu) << 8) + s0, b1 = ((c1 & 0x7fffu) << 8) + s1; // LRM_TT_SUB^2 = 256 entries per block
-    static_assert(LRM_TT_SUB * LRM_TT_SUB == 256, "fine block size");
-    const uint32_t f0 = lrm_tt_cell(cells, r0 ? b0 : fbase), f1 = lrm_tt_cell(cells, r1 ? b1 : fbase);
-    code0 = r0 ? f0 : c0;
-    code1 = r1 ? f1 : c1;
+    s0 = sz + sx0;
+    s1 = sz + sx1;
+    fbase_out = fbase;
     // The bounds.  Inner grid: one entry per 2 x 2 coarse cells, d0 + unit (gx sx + gz sz) over its 16 x 16 sub-cells, the two
     // products of signed bytes in one v_dot4 (bytes 2 and 3 of the entry), from LDS.  Outer grid: the distance beyond the circle
     // that holds every target and every valid point -- far from the workspace that is nearly the distance itself, and it costs no
@@ -365,11 +362,20 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float band, flo
         const float o1 = fmaxf(LRM_FAST_SQRT(__builtin_fmaf(x1, x1, zz)) - G.r_outer, 0.f);
         lb0 = far ? o0 : lb0;
         lb1 = far ? o1 : lb1;
-        code0 = out0 ? (uint32_t)LRM_TT_UNANSWERED : code0;
-        code1 = out1 ? (uint32_t)LRM_TT_UNANSWERED : code1;
+        c0 = out0 ? (uint32_t)LRM_TT_UNANSWERED : c0; // (not a refined cell: resolves to itself)
+        c1 = out1 ? (uint32_t)LRM_TT_UNANSWERED : c1;
         lb0 = out0 ? 0.f : lb0;
         lb1 = out1 ? 0.f : lb1;
     }
+}
+// The code of a plane point from its coarse entry c and sub-cell place s (lrm_toltab_lookup2): the entry itself, or, of a refined cell,
+// the sub-cell's entry in the cell's block -- one more 2-byte load, issued by every lane (the others read the grid's first fine entry).
+LRM_HD uint32_t lrm_toltab_resolve(const LrmTolTabView& G, uint32_t c, uint32_t s, uint32_t fbase) {
+    const bool r = (c & 0x8000u) != 0u;
+    const uint32_t b = ((c & 0x7fffu) << 8) + s; // LRM_TT_SUB^2 = 256 entries per block
+    static_assert(LRM_TT_SUB * LRM_TT_SUB == 256, "fine block size");
+    const uint32_t f = lrm_tt_cell(G.cells, r ? b : fbase);
+    return r ? f : c;
 }
 // lrm_tol_plane restricted to what the cell's code names: at most two clamp targets, one circle's point validity.
 // Same arithmetic as lrm_tol_plane on those operands.  x = abscissa - coxa_length.
@@ -467,11 +473,11 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     const bool far = !(fmaxf(r + L.coxa_length, fabsf(z)) < G.far_limit);
     const bool anyfar = LRM_TOL_ANY(far);
     const float xD = uD - L.coxa_length, xF = uF - L.coxa_length;
-    uint32_t cellD, cellF;
+    uint32_t cD, cF, sD, sF, fbase;
     float lbD, lbF;
     bool band_doubt;
-    if (anyfar) lrm_toltab_lookup2<true>(G, far, band, xD, xF, z, cellD, cellF, lbD, lbF, band_doubt);
-    else lrm_toltab_lookup2<false>(G, false, band, xD, xF, z, cellD, cellF, lbD, lbF, band_doubt);
+    if (anyfar) lrm_toltab_lookup2<true>(G, far, band, xD, xF, z, cD, cF, sD, sF, fbase, lbD, lbF, band_doubt);
+    else lrm_toltab_lookup2<false>(G, false, band, xD, xF, z, cD, cF, sD, sF, fbase, lbD, lbF, band_doubt);
     lu |= band_doubt ? LRM_TD_YAW : 0u;
     // Which candidate first: the one with the smaller lower bound w^2 + lb^2 of its squared distance (lb: the cell's bound of
     // the in-plane part).  A candidate that may be valid has lb = 0; inside the yaw range (w = 0) its bound is 0 and it goes
@@ -481,7 +487,7 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     const bool firstD = inF ? (bD < bF) : (bD <= bF);
     const uint32_t code0 = firstD ? codeD : codeF;
     const float w0 = firstD ? wD : wF, x0 = firstD ? xD : xF;
-    const uint32_t cell0 = firstD ? cellD : cellF;
+    const uint32_t cell0 = lrm_toltab_resolve(G, firstD ? cD : cF, firstD ? sD : sF, fbase); // only the candidate that is evaluated
     const float b1 = firstD ? bF : bD;
     const bool lim0 = code0 >= 2u;
     const bool in0 = firstD ? inD : inF;
@@ -530,7 +536,8 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
 #if !defined(__HIP_DEVICE_COMPILE__)
         lrm_tab_host_seconds++;
 #endif
-        const uint32_t code1 = firstD ? codeF : codeD, cell1 = firstD ? cellF : cellD; // the other candidate's operands: selected here, where they are needed
+        const uint32_t code1 = firstD ? codeF : codeD; // the other candidate's operands: selected here, where they are needed
+        const uint32_t cell1 = lrm_toltab_resolve(G, firstD ? cF : cD, firstD ? sF : sD, fbase);
         const float w1 = firstD ? wF : wD, x1 = firstD ? xF : xD;
         const bool lim1 = code1 >= 2u;
         float du1, dz1;
