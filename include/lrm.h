@@ -349,6 +349,12 @@ int lrm_dbg_tol_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg
  * points whose second yaw candidate had to be evaluated (its lower bound did not exclude it). */
 int lrm_dbg_toltab_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                         uint8_t* mask_out, float* dxyz_out, uint32_t* doubt_out, uint32_t* stats_out);
+/* The bit-exact table-guided evaluation (csrc/lrm_point_xtab.h: decisions from the plane table, values in the reference's
+ * operation order) on the host, WITHOUT the re-evaluation of its doubtful points: every point with doubt 0 carries the mask and
+ * the vector of lrm_reach_cpu / lrm_dist_cpu bit for bit (tests/test_xtab_cpu.py).  stats_out[2] (or NULL): points whose
+ * second value chain ran, table bytes. */
+int lrm_dbg_xtab_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+                      uint8_t* mask_out, float* dxyz_out, uint32_t* doubt_out, uint32_t* stats_out);
 /* The plane table's lower bound of the in-plane distance at n plane points xz[2 n] (abscissa - coxa_length, z), next to the
  * full plane evaluation there: distance sqrt(du^2 + dz^2), validity, doubt bits.  The bound must not exceed the distance
  * of an invalid point and must be 0 at a valid one (tests/test_tol_cpu.py). */

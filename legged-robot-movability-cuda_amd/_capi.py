@@ -84,6 +84,7 @@ def load():
         "lrm_dbg_tol_queue_counts": [vp, vp, vp],
         "lrm_dbg_toltab_host": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_toltab_bounds": [vp, sz, vp, vp, vp, vp, vp, vp],
+        "lrm_dbg_xtab_host": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_shard_bounds": [sz, C.c_int, C.c_int, sz, vp, vp],
         "lrm_dbg_pair_counts": [vp],
         "lrm_tol_prepare": [vp, vp, sz, vp],
@@ -431,6 +432,18 @@ def dbg_toltab_host(xyz, leg, quat=None):
                                      _ptr(doubt), _ptr(stats)))
     return mask, d, doubt, dict(rows=int(stats[0]), vrows=int(stats[1]), refined=int(stats[2]), bytes=int(stats[3]),
                                 second_candidates=int(stats[4]))
+
+
+def dbg_xtab_host(xyz, leg, quat=None):
+    """the bit-exact table-guided evaluation (csrc/lrm_point_xtab.h) on the host, no re-evaluation of its doubtful
+    points -> (mask, vectors, doubt bits, dict(second_chains, bytes))"""
+    xyz = _f32(xyz, (-1, 3))
+    n = len(xyz)
+    mask, d, doubt = np.zeros(n, np.uint8), np.zeros_like(xyz), np.zeros(n, np.uint32)
+    stats = np.zeros(2, np.uint32)
+    check(load().lrm_dbg_xtab_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d),
+                                   _ptr(doubt), _ptr(stats)))
+    return mask, d, doubt, dict(second_chains=int(stats[0]), bytes=int(stats[1]))
 
 
 def dbg_toltab_bounds(xz, leg, quat=None):

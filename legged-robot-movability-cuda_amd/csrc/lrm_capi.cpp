@@ -20,6 +20,7 @@
 #include "lrm_point.h"
 #include "lrm_point_fast.h"
 #include "lrm_point_tol.h"
+#include "lrm_point_xtab.h"
 
 namespace {
 
@@ -46,7 +47,10 @@ int hip_fail(hipError_t e, const char* where) {
 
 const float* quat_or_default(const float* q) { return q ? q : kQuatTest; }
 
-// ---- LRM_MODE_TOL plumbing ---------------------------------------------------------------------
+// ---- table-guided modes: plumbing ---------------------------------------------------------------
+// One lock around the process-wide caches below (table cache with LRU eviction, queue workspaces, the statistic of the last
+// call): host threads may call the entry points concurrently; a table is never freed under a launch that is being queued.
+std::recursive_mutex g_cache_mu;
 // The tolerance block of a (leg, quaternion) costs a few hundred microseconds of host geometry (arc
 // intersections + their verification, lrm_compile_tol): a small cache keyed by the 18 input floats.
 struct TolKey {
@@ -55,13 +59,16 @@ struct TolKey {
 };
 struct TolEntry {
     LrmTolLeg tl;
+    LrmXtabLeg xl;                 // the strict value chain's constants (lrm_point_xtab.h)
     std::vector<uint8_t> tab;      // the plane table (lrm_build_tol_tab), built on first use
     int tab_state = 0;             // 0 not built yet, 1 built, -1 this leg has none (too many rows)
+    float tab_build_ms = 0.f;      // what building it cost (host wall clock, or the device build's events)
     std::map<int, uint8_t*> tab_dev;
     uint64_t last_use = 0;
 };
 uint64_t g_tol_clock = 0;
 std::map<TolKey, TolEntry> g_tol_cache;
+float g_last_tab_build_ms = -1.f; // lrm_dbg_last_table_build_ms
 TolEntry& tol_entry(const LrmLegDimensions& leg, const float* quat, const LrmCompiledLeg& L) {
     TolKey k;
     std::memcpy(k.v, &leg, 14 * sizeof(float));
@@ -81,30 +88,58 @@ TolEntry& tol_entry(const LrmLegDimensions& leg, const float* quat, const LrmCom
     TolEntry& e = g_tol_cache[k];
     e.last_use = ++g_tol_clock;
     lrm_compile_tol(L, &e.tl);
+    lrm_make_xtab_leg(L, e.tl, &e.xl);
     return e;
 }
-// where the last tolerance-mode launch left its per-workgroup doubt counts, for lrm_dbg_tol_queue_counts
+// where the last tolerance-mode launch left its per-segment doubt counts, for lrm_dbg_tol_queue_counts
 struct TolLast {
     int dev = -1;
     const uint32_t* counts = nullptr; // device: one count per queue segment of the main kernel
     size_t blocks = 0, n = 0;         // segments, points
     uint32_t cap = 0;                 // slots per segment
 } g_tol_last;
-// Device workspace of the doubt queues (rewritten by every call), one per (device, stream) in use, grown on demand.
+// Device workspace of the doubt queues (rewritten by every call), one per (device, stream) in use, grown on demand.  Streams come
+// and go (a caller rotating streams; lrm_reach_dist_multi's per-call streams drop theirs explicitly): the map keeps the
+// kMaxWorkspaces most recently used entries, and an entry is looked up by the stream's address only while that stream lives.
 struct TolWorkspace {
     uint32_t* p = nullptr;
     size_t words = 0;
+    uint64_t last_use = 0;
 };
+constexpr size_t kMaxWorkspaces = 16;
 std::map<std::pair<int, void*>, TolWorkspace> g_tol_ws;
+void tol_workspace_free(TolWorkspace& w) {
+    if (w.p && g_tol_last.counts == w.p) g_tol_last = TolLast{}; // the statistic of the last call goes with its workspace
+    if (w.p) (void)hipFree(w.p); // synchronises with whatever still uses it
+    w = TolWorkspace{};
+}
+// the workspace of a stream that is about to be destroyed (call on its device, after the stream has drained)
+void tol_workspace_drop(int dev, void* stream) {
+    std::lock_guard<std::recursive_mutex> g(g_cache_mu);
+    auto it = g_tol_ws.find(std::make_pair(dev, stream));
+    if (it == g_tol_ws.end()) return;
+    tol_workspace_free(it->second);
+    g_tol_ws.erase(it);
+}
 int tol_workspace(size_t words, void* stream, uint32_t** out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
-    TolWorkspace& w = g_tol_ws[std::make_pair(dev, stream)];
+    const auto key = std::make_pair(dev, stream);
+    if (g_tol_ws.find(key) == g_tol_ws.end() && g_tol_ws.size() >= kMaxWorkspaces) { // the least recently used entry goes
+        auto old = g_tol_ws.begin();
+        for (auto jt = g_tol_ws.begin(); jt != g_tol_ws.end(); ++jt)
+            if (jt->second.last_use < old->second.last_use) old = jt;
+        int cur = dev;
+        (void)hipSetDevice(old->first.first);
+        tol_workspace_free(old->second);
+        (void)hipSetDevice(cur);
+        g_tol_ws.erase(old);
+    }
+    TolWorkspace& w = g_tol_ws[key];
+    w.last_use = ++g_tol_clock;
     if (words > w.words) {
-        if (w.p && g_tol_last.counts == w.p) g_tol_last = TolLast{}; // the statistic of the last call goes with its workspace
-        if (w.p) (void)hipFree(w.p); // synchronises with whatever still uses it
-        w.p = nullptr;
-        w.words = 0;
+        tol_workspace_free(w);
+        w.last_use = g_tol_clock;
         void* p = nullptr;
         const size_t want = words + words / 4;
         HIP_TRY(hipMalloc(&p, want * sizeof(uint32_t)), "hipMalloc tolerance-mode queues");
@@ -114,9 +149,9 @@ int tol_workspace(size_t words, void* stream, uint32_t** out) {
     *out = w.p;
     return LRM_OK;
 }
-// The table kernel (dist_tab_kernel) is the default of LRM_MODE_TOL from LRM_TOLTAB_MIN_POINTS points on (building the
-// table costs a few milliseconds of host geometry per (leg, orientation)); LRM_TOL_TABLE=0 in the environment keeps
-// the staged kernel (A/B runs).
+// The table kernels (dist_tab_kernel, dist_xtab_kernel) are the default of their modes from LRM_TOLTAB_MIN_POINTS points on
+// (below, a call is launch-bound and the single launch of the kernels without a table wins); LRM_TOL_TABLE=0 in the
+// environment keeps the kernels without a table (A/B runs).
 #ifndef LRM_TOLTAB_MIN_POINTS
 #define LRM_TOLTAB_MIN_POINTS 200000
 #endif
@@ -127,10 +162,22 @@ bool tol_tab_wanted(size_t n) {
     if (e && e[0] == '2') return n > 0;
     return n >= (size_t)LRM_TOLTAB_MIN_POINTS;
 }
+// LRM_MODE_FAST takes the table-guided bit-exact kernel (dist_xtab_kernel) wherever the tolerance mode would take its table
+// kernel; LRM_XTAB=0 keeps the filtered kernel of rounds 1-3 (A/B runs, and the reference the new kernel is tested against).
+bool xtab_wanted(size_t n) {
+    const char* e = std::getenv("LRM_XTAB");
+    if (e && e[0] == '0') return false;
+    return tol_tab_wanted(n);
+}
 // device copy of the table of E on the current device, or null (no table for this leg); rc != LRM_OK on a HIP error
-int tol_tab_device(TolEntry& E, const uint8_t** out) {
+int tol_tab_device(TolEntry& E, void* stream, const uint8_t** out) {
     *out = nullptr;
-    if (E.tab_state == 0) E.tab_state = lrm_build_tol_tab(E.tl, &E.tab) ? 1 : -1;
+    if (E.tab_state == 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        E.tab_state = lrm_build_tol_tab(E.tl, &E.tab) ? 1 : -1;
+        E.tab_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        g_last_tab_build_ms = E.tab_build_ms;
+    }
     if (E.tab_state < 0) return LRM_OK;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
@@ -141,63 +188,68 @@ int tol_tab_device(TolEntry& E, const uint8_t** out) {
         td = static_cast<uint8_t*>(p);
         HIP_TRY(hipMemcpy(td, E.tab.data(), E.tab.size(), hipMemcpyHostToDevice), "hipMemcpy plane table");
     }
+    (void)stream;
     *out = td;
     return LRM_OK;
 }
-// distance / fused launch of the SoA kernels in the current mode. op: 1 distance, 2 reach + distance
+// distance / fused launch in the current mode, SoA (xyz_aos null) or the float3 arrays of the apply_kernel boundary (xyz_aos set:
+// x, y, z, bits, dy, dz unused, dx = the float3 output).  op: 1 distance, 2 reach + distance
+int launch_dist_any(int op, const float* xyz_aos, const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions& leg,
+                    const float* quat, const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
+                    float* dz, void* stream) {
+    std::lock_guard<std::recursive_mutex> g(g_cache_mu);
+    const int mode = g_mode;
+    hipStream_t st = (hipStream_t)stream;
+    const bool tolm = mode == LRM_MODE_TOL || mode == LRM_MODE_TOL_REL;
+    // 32-bit point indices in the table kernels (n + one grid stride < 2^32; LRM_MODE_TOL_REL keeps bit 31 of a queue record for a flag)
+    const bool fits = n < (mode == LRM_MODE_TOL_REL ? 0x80000000ull : 0xc0000000ull);
+    if ((tolm || (mode == LRM_MODE_FAST && xtab_wanted(n))) && L.fast_ok && fits) {
+        TolEntry& E = tol_entry(leg, quat, L);
+        const LrmTolLeg& TL = E.tl;
+        if (TL.tol_ok) {
+            const uint8_t* tab = nullptr;
+            if (tol_tab_wanted(n)) {
+                const int rc = tol_tab_device(E, stream, &tab);
+                if (rc != LRM_OK) return rc;
+            }
+            if (tolm || tab) {
+                uint32_t* w = nullptr;
+                const int rc = tol_workspace(tab ? lrm_tol_tab_queue_words(n) : lrm_tol_queue_words(n), stream, &w);
+                if (rc != LRM_OK) return rc;
+                if (!tolm) {
+                    if (xyz_aos) HIP_TRY(lrm_launch_dist_xtab_aos(op, xyz_aos, n, L, E.xl, tab, mask, dx, w, st), "table-guided bit-exact launch");
+                    else HIP_TRY(lrm_launch_dist_xtab(op, x, y, z, n, L, E.xl, tab, mask, bits, dx, dy, dz, w, st), "table-guided bit-exact launch");
+                } else if (tab) {
+                    if (xyz_aos) HIP_TRY(lrm_launch_dist_tab_aos(op, xyz_aos, n, L, TL, E.xl, tab, mask, dx, w, tol_flags(), st), "tolerance-mode (table) launch");
+                    else HIP_TRY(lrm_launch_dist_tab(op, x, y, z, n, L, TL, E.xl, tab, mask, bits, dx, dy, dz, w, tol_flags(), st), "tolerance-mode (table) launch");
+                } else {
+                    if (xyz_aos) HIP_TRY(lrm_launch_dist_tol_aos(op, xyz_aos, n, L, TL, mask, dx, w, tol_flags(), st), "tolerance-mode launch");
+                    else HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, tol_flags(), st), "tolerance-mode launch");
+                }
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                // the workspace starts with one count per segment
+                if (tab && mode == LRM_MODE_TOL_REL) g_tol_last = TolLast{dev, w, lrm_tol_tab_segments(n) * 4, n, (uint32_t)LRM_TOL_TAB_SEG_CAP / 4};
+                else if (tab) g_tol_last = TolLast{dev, w, lrm_tol_tab_segments(n), n, (uint32_t)LRM_TOL_TAB_SEG_CAP};
+                else g_tol_last = TolLast{dev, w, lrm_tol_queue_words(n) / (4 * LRM_TOL_SEG_CAP_WORDS + 4), n, (uint32_t)LRM_TOL_SEG_CAP_WORDS};
+                return LRM_OK;
+            }
+        }
+    }
+    g_tol_last = TolLast{}; // this call ran the kernels without a table and without a queue: no queue statistic
+    if (xyz_aos) HIP_TRY(lrm_launch_dist_aos(op, xyz_aos, n, L, mask, dx, mode != LRM_MODE_STRICT, st), "Kernel launch");
+    else HIP_TRY(lrm_launch_dist_soa(op, x, y, z, n, L, mask, bits, dx, dy, dz, mode != LRM_MODE_STRICT, st), "distance launch");
+    return LRM_OK;
+}
 int launch_dist_mode(int op, const float* x, const float* y, const float* z, size_t n, const LrmLegDimensions& leg,
                      const float* quat, const LrmCompiledLeg& L, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                      float* dz, void* stream) {
-    if (tol_mode() && L.fast_ok && n < 0xc0000000ull) { // 32-bit point indices in the tolerance kernels (n + one grid stride < 2^32)
-        TolEntry& E = tol_entry(leg, quat, L);
-        const LrmTolLeg& TL = E.tl;
-        if (TL.tol_ok) {
-            const uint8_t* tab = nullptr;
-            if (tol_tab_wanted(n)) {
-                const int rc = tol_tab_device(E, &tab);
-                if (rc != LRM_OK) return rc;
-            }
-            uint32_t* w = nullptr;
-            const int rc = tol_workspace(tab ? lrm_tol_tab_queue_words(n) : lrm_tol_queue_words(n), stream, &w);
-            if (rc != LRM_OK) return rc;
-            if (tab) HIP_TRY(lrm_launch_dist_tab(op, x, y, z, n, L, TL, tab, mask, bits, dx, dy, dz, w, tol_flags(), (hipStream_t)stream), "tolerance-mode (table) launch");
-            else HIP_TRY(lrm_launch_dist_tol(op, x, y, z, n, L, TL, mask, bits, dx, dy, dz, w, tol_flags(), (hipStream_t)stream), "tolerance-mode launch");
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            // the workspace starts with one count per segment
-            if (tab) g_tol_last = TolLast{dev, w, lrm_tol_tab_segments(n), n, (uint32_t)LRM_TOL_TAB_SEG_CAP};
-            else g_tol_last = TolLast{dev, w, lrm_tol_queue_words(n) / (4 * LRM_TOL_SEG_CAP_WORDS + 4), n, (uint32_t)LRM_TOL_SEG_CAP_WORDS};
-            return LRM_OK;
-        }
-    }
-    g_tol_last = TolLast{}; // this call ran the bit-exact kernels (mode, or a leg outside the tolerance mode's eligibility): no queue statistic
-    HIP_TRY(lrm_launch_dist_soa(op, x, y, z, n, L, mask, bits, dx, dy, dz, g_mode != LRM_MODE_STRICT, (hipStream_t)stream),
-            "distance launch");
-    return LRM_OK;
+    return launch_dist_any(op, nullptr, x, y, z, n, leg, quat, L, mask, bits, dx, dy, dz, stream);
 }
-
 // distance / fused launch on the float3 arrays of the apply_kernel boundary in the current mode
 int launch_dist_aos_mode(int op, const float* xyz, size_t n, const LrmLegDimensions& leg, const float* quat, const LrmCompiledLeg& L,
                          uint8_t* mask, float* dxyz, void* stream) {
-    if (tol_mode() && L.fast_ok && n < 0xc0000000ull) {
-        TolEntry& E = tol_entry(leg, quat, L);
-        const LrmTolLeg& TL = E.tl;
-        if (TL.tol_ok) {
-            const uint8_t* tab = nullptr;
-            if (tol_tab_wanted(n)) {
-                const int rc = tol_tab_device(E, &tab);
-                if (rc != LRM_OK) return rc;
-            }
-            uint32_t* w = nullptr;
-            const int rc = tol_workspace(tab ? lrm_tol_tab_queue_words(n) : lrm_tol_queue_words(n), stream, &w);
-            if (rc != LRM_OK) return rc;
-            if (tab) HIP_TRY(lrm_launch_dist_tab_aos(op, xyz, n, L, TL, tab, mask, dxyz, w, tol_flags(), (hipStream_t)stream), "tolerance-mode (table) launch");
-            else HIP_TRY(lrm_launch_dist_tol_aos(op, xyz, n, L, TL, mask, dxyz, w, tol_flags(), (hipStream_t)stream), "tolerance-mode launch");
-            return LRM_OK;
-        }
-    }
-    HIP_TRY(lrm_launch_dist_aos(op, xyz, n, L, mask, dxyz, g_mode != LRM_MODE_STRICT, (hipStream_t)stream), "Kernel launch");
-    return LRM_OK;
+    return launch_dist_any(op, xyz, nullptr, nullptr, nullptr, n, leg, quat, L, mask, nullptr, dxyz, nullptr, nullptr, stream);
 }
 
 // RAII device buffer for the host-buffer entry points
@@ -1036,6 +1088,39 @@ int lrm_dbg_toltab_host(const float* xyz, size_t n, const LrmLegDimensions* leg,
     if (stats_out) stats_out[4] = (uint32_t)std::min<unsigned long long>(lrm_tab_host_seconds, 0xffffffffull);
     return LRM_OK;
 }
+// The bit-exact table-guided evaluation (lrm_point_xtab.h) on the host, WITHOUT the re-evaluation of its doubtful points:
+// every point with doubt 0 must equal lrm_dist_cpu / lrm_reach_cpu bit for bit.  stats_out[2] (optional): points whose second
+// chain (twin or second candidate) ran, table bytes
+int lrm_dbg_xtab_host(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
+                      float* dxyz_out, uint32_t* doubt_out, uint32_t* stats_out) {
+    if (!leg || (n && (!xyz || !mask_out || !dxyz_out || !doubt_out))) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    LrmTolLeg TL;
+    lrm_compile_tol(L, &TL);
+    if (!TL.tol_ok) return fail(LRM_EINVAL, "leg not eligible for the table-guided modes");
+    std::vector<uint8_t> tab;
+    if (!lrm_build_tol_tab(TL, &tab)) return fail(LRM_EINVAL, "leg needs more table rows than a cell code can name");
+    const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab.data());
+    const LrmTolTabView G = lrm_toltab_view(tab.data(), hd->rows, hd->vrows, lrm_toltab_bound_inner(tab.data()), TL.r_outer);
+    LrmXtabLeg X;
+    lrm_make_xtab_leg(L, TL, &X);
+    lrm_xtab_host_seconds = 0;
+    for (size_t i = 0; i < n; i++) {
+        LrmVec3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        uint32_t doubt = 0;
+        mask_out[i] = lrm_xtab_point(X, G, p, doubt);
+        dxyz_out[3 * i] = p.x;
+        dxyz_out[3 * i + 1] = p.y;
+        dxyz_out[3 * i + 2] = p.z;
+        doubt_out[i] = doubt;
+    }
+    if (stats_out) {
+        stats_out[0] = (uint32_t)std::min<unsigned long long>(lrm_xtab_host_seconds, 0xffffffffull);
+        stats_out[1] = (uint32_t)tab.size();
+    }
+    return LRM_OK;
+}
 // The table's lower bound of the in-plane distance at plane points (x = abscissa - coxa_length, z) of the INNER grid, next
 // to what the full plane evaluation (lrm_tol_plane) finds there: tests/test_tol_cpu.py checks bound <= distance.
 int lrm_dbg_toltab_bounds(const float* xz, size_t n, const LrmLegDimensions* leg, const float* quat, float* lb_out,
@@ -1085,6 +1170,7 @@ int lrm_dbg_pair_counts(uint64_t out[4]) {
 // all re-evaluated).  Valid until the next tolerance-mode call on a larger cloud regrows the workspace.
 int lrm_dbg_tol_queue_counts(uint64_t* n_points, uint64_t* n_queued, uint64_t* n_overflowed) {
     if (!n_points || !n_queued || !n_overflowed) return fail(LRM_EINVAL, "null argument");
+    std::lock_guard<std::recursive_mutex> g(g_cache_mu);
     if (!g_tol_last.counts) return fail(LRM_EINVAL, "no tolerance-mode call on device buffers yet");
     int cur = 0;
     HIP_TRY(hipGetDevice(&cur), "hipGetDevice");
@@ -1412,6 +1498,7 @@ struct MultiState { // releases everything on every exit path
         for (auto& m : d) {
             if (hipSetDevice(m.dev) != hipSuccess) continue;
             if (m.st) (void)hipStreamSynchronize(m.st);
+            if (m.st) tol_workspace_drop(m.dev, (void*)m.st); // the queue workspace keyed by this call's stream goes with the stream
             for (void* p : {m.in, m.mask, m.out, m.words, m.gathered})
                 if (p) (void)hipFree(p);
             if (m.a) (void)hipEventDestroy(m.a);
@@ -1434,11 +1521,12 @@ int lrm_tol_prepare(const LrmLegDimensions* leg, const float* quat, size_t n_max
     LrmCompiledLeg L;
     lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
     if (!L.fast_ok) return LRM_OK; // this leg runs the strict kernels in every mode: nothing to prepare
+    std::lock_guard<std::recursive_mutex> g(g_cache_mu);
     TolEntry& E = tol_entry(*leg, quat_or_default(quat), L);
     if (!E.tl.tol_ok) return LRM_OK; // falls back to LRM_MODE_FAST
     const uint8_t* tab = nullptr;
     if (tol_tab_wanted(n_max)) {
-        const int rc = tol_tab_device(E, &tab);
+        const int rc = tol_tab_device(E, stream, &tab);
         if (rc != LRM_OK) return rc;
     }
     uint32_t* w = nullptr;
@@ -1446,6 +1534,7 @@ int lrm_tol_prepare(const LrmLegDimensions* leg, const float* quat, size_t n_max
 }
 
 void lrm_release_workspaces(void) {
+    std::lock_guard<std::recursive_mutex> g(g_cache_mu);
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     for (auto& w : g_tol_ws) {
@@ -1558,12 +1647,14 @@ int lrm_reach_dist_multi(const float* xyz, size_t n, const LrmLegDimensions* leg
     // 2. the exchange: every device receives every shard's words (grouped: one collective over all communicators)
     if (use_rccl) {
         int rc = g_rccl.GroupStart();
-        for (int d = 0; d < ndev && rc == 0; d++) {
+        hipError_t he = hipSuccess;
+        for (int d = 0; d < ndev && rc == 0 && he == hipSuccess; d++) {
             MultiDev& m = S.d[d];
-            HIP_TRY(hipSetDevice(m.dev), "hipSetDevice");
-            rc = g_rccl.AllGather(m.words, m.gathered, per_words, kNcclUint64, g_multi.comms[d], m.st);
+            he = hipSetDevice(m.dev);
+            if (he == hipSuccess) rc = g_rccl.AllGather(m.words, m.gathered, per_words, kNcclUint64, g_multi.comms[d], m.st);
         }
-        const int rc2 = g_rccl.GroupEnd();
+        const int rc2 = g_rccl.GroupEnd(); // on every path: a group left open would hang the process's next RCCL call
+        HIP_TRY(he, "hipSetDevice");
         if (rc != 0 || rc2 != 0) return fail(LRM_ENODEV, (std::string("ncclAllGather: ") + g_rccl.GetErrorString(rc ? rc : rc2)).c_str());
     } else {
         MultiDev& m = S.d[0];

@@ -37,11 +37,18 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
 // Table variant (dist_tab_kernel + the same fix-up): tab_dev = device copy of lrm_build_tol_tab's table for TL.
 size_t lrm_tol_tab_queue_words(size_t n);
 size_t lrm_tol_tab_segments(size_t n); // the workspace starts with one count per segment
+struct LrmXtabLeg; // lrm_point_xtab.h
 hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
-                               const LrmTolLeg& TL, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
+                               const LrmTolLeg& TL, const LrmXtabLeg& X, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                                float* dz, uint32_t* workspace, uint32_t flags, hipStream_t st);
-hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const uint8_t* tab_dev,
+hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const LrmXtabLeg& X, const uint8_t* tab_dev,
                                    uint8_t* mask, float* dxyz, uint32_t* workspace, uint32_t flags, hipStream_t st);
+// LRM_MODE_FAST through the plane table (dist_xtab_kernel, lrm_point_xtab.h: decisions from the table, values in the reference's
+// order, bit-identical to LRM_MODE_STRICT) + tol_fixup_kernel for its doubtful points.  Workspace: lrm_tol_tab_queue_words(n).
+hipError_t lrm_launch_dist_xtab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L, const LrmXtabLeg& X,
+                                const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace, hipStream_t st);
+hipError_t lrm_launch_dist_xtab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmXtabLeg& X, const uint8_t* tab_dev,
+                                    uint8_t* mask, float* dxyz, uint32_t* workspace, hipStream_t st);
 hipError_t lrm_launch_reach_aos(const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask, bool fast,
                                 hipStream_t st);
 hipError_t lrm_launch_dist_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, uint8_t* mask,

@@ -33,6 +33,7 @@
 #include "lrm_point.h"
 #include "lrm_point_fast.h"
 #include "lrm_point_tol.h"
+#include "lrm_point_xtab.h"
 
 #ifndef LRM_TOL_MIN_WAVES
 #define LRM_TOL_MIN_WAVES 8 // the staged kernel needs 59 VGPRs; its barriers like occupancy: 6 / 7 / 8 waves -> 123.0 / 122.3 / 119.9 us per step
@@ -329,6 +330,8 @@ struct TabLds {
     LrmTabVRow vrows[32];
 };
 constexpr int kTabSegCap = LRM_TOL_TAB_SEG_CAP; // doubt slots per workgroup of dist_tab_kernel
+constexpr int kWaveSegCap = LRM_TOL_TAB_SEG_CAP / (LRM_TOL_BLOCK / 64); // ... per wave in LRM_MODE_TOL_REL (the same workspace, cut four ways)
+static_assert(kWaveSegCap * (LRM_TOL_BLOCK / 64) == LRM_TOL_TAB_SEG_CAP, "wave segments tile a workgroup's segment");
 constexpr int kTabBoundVecs = LRM_TT_NB * LRM_TT_NB * 4 / 16; // 16-byte pieces of the inner grid's bounds
 static_assert(kTabBoundVecs % kBlock == 0, "every thread stages the same number of pieces");
 // kShort: LRM_MODE_TOL_REL (a template argument: as a run-time flag the compiler computes the norm for every point of every mode)
@@ -374,6 +377,13 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
     const uint32_t n32 = (uint32_t)n; // the C ABI sends clouds of 0xc0000000 points and more to the bit-exact kernels: indices fit 32 bits
     QueueRec* seg = queue + (size_t)blockIdx.x * kTabSegCap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // LRM_MODE_TOL_REL queues ~5 % of a random cloud: nearly every wave pushes in every round.  Its segments belong to WAVES
+    // (kWaveSegCap slots each, the count in a scalar register: no LDS atomic, no wait on its return in every wave's chain, no
+    // barrier at the end); a record's bit 31 says that a DECISION was in doubt (filtered code), clear = the vector is merely short
+    // (the table-guided bit-exact chain of lrm_point_xtab.h takes it).
+    const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane(wave); // the compiler cannot know that threadIdx.x >> 6 is uniform: without this the segment's address lives in two VGPRs
+    QueueRec* wseg = queue + ((size_t)blockIdx.x * (kBlock / 64) + (size_t)wave_s) * kWaveSegCap;
+    uint32_t wq = 0;
     const uint32_t toff0 = threadIdx.x * 4u;
     uint32_t round = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride, round++) {
@@ -390,12 +400,12 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
         }
         uint32_t doubt = 0;
         const LrmVec3 p_in = p; // kept for the queue record (three registers; re-loading it cost a pushing wave an L2 round trip)
-        const float short_mm = lrm_tol_rel_threshold(L, p); // (of the point, before it becomes the vector)
         const bool m = lrm_tab_point(L, G, p, doubt) && live;
         doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u; // selftest: every point goes to the fix-up
-        if (kShort) { // LRM_MODE_TOL_REL: a vector shorter than the threshold comes from the bit-exact code
+        if (kShort) { // LRM_MODE_TOL_REL: a vector shorter than the threshold comes from the bit-exact code; bit 31 = a decision was in doubt
             const float nn = __builtin_fmaf(p.x, p.x, __builtin_fmaf(p.y, p.y, p.z * p.z));
-            doubt |= (live && !(nn >= short_mm * short_mm)) ? 1u : 0u;
+            const float short_mm = lrm_tol_rel_threshold(L, p_in); // (from the point kept for the queue record: nothing more stays live across the evaluation)
+            doubt = (doubt ? 0x80000000u : 0u) | ((live && !(nn >= short_mm * short_mm)) ? 1u : 0u);
         }
         if (live) {
             if (kAoS) {
@@ -414,7 +424,15 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
             if (lane == 0) lrm_at(bits + (rbase >> 6), lrm_opaque((uint32_t)wave * 8u)) = w;
         }
         const uint64_t dm = __ballot(doubt != 0);
-        if (dm) {
+        if (kShort) {
+            if (dm) {
+                if (doubt) {
+                    const uint32_t qs = wq + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+                    if (qs < (uint32_t)kWaveSegCap) wseg[qs] = QueueRec{i | (doubt & 0x80000000u), p_in.x, p_in.y, p_in.z}; // beyond: the count tells the fix-up to redo the wave's points
+                }
+                wq += (uint32_t)__popcll(dm);
+            }
+        } else if (dm) {
             uint32_t qb = 0;
             if (lane == 0) qb = atomicAdd(&s_qn, (uint32_t)__popcll(dm));
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
@@ -424,11 +442,121 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
             }
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
+    if (kShort) {
+        if (lane == 0) counts[blockIdx.x * (kBlock / 64) + wave_s] = wq;
+    } else {
+        __syncthreads();
+        if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
+    }
 #if defined(LRM_FIX_TRACE)
     if (threadIdx.x == 0 && blockIdx.x < 32768) g_main_trace[blockIdx.x * 2 + 1] = wall_clock64();
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LRM_MODE_FAST through the plane table (round 4; lrm_point_xtab.h): the DECISIONS of distance_global come from the table
+// exactly as in dist_tab_kernel, the VALUES from the reference's own operations in the reference's own order -- the outputs
+// are bit-identical to LRM_MODE_STRICT.  A point with a decision inside its band (0.3 % of a random cloud) is queued for
+// tol_fixup_kernel, i.e. the filtered code this kernel replaces for everybody else.  Same launch shape, staging and queue
+// as dist_tab_kernel.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef LRM_XTAB_MIN_WAVES
+#define LRM_XTAB_MIN_WAVES 5
+#endif
+struct KernargXtab {
+    const float *x, *y, *z;
+    size_t n;
+    LrmXtabLeg X;
+};
+constexpr unsigned kXtabLegArg = (unsigned)offsetof(KernargXtab, X);
+static_assert(kXtabLegArg == 32, "kernarg layout");
+template <int kOp, bool kAoS = false>
+__global__ __launch_bounds__(kBlock, LRM_XTAB_MIN_WAVES) void dist_xtab_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
+    const LrmXtabLeg X_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
+    float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ tab, QueueRec* __restrict__ queue,
+    uint32_t* __restrict__ counts, uint32_t selftest) {
+    __shared__ TabLds s_tab;
+    __shared__ uint32_t s_bound[LRM_TT_NB * LRM_TT_NB];
+    __shared__ uint32_t s_qn;
+    const LrmXtabLeg& X = lrm_kernarg<LrmXtabLeg>(kXtabLegArg);
+    const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
+    LrmVec3 p_next{0.f, 0.f, 0.f};
+    {
+        const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x;
+        const size_t rb0 = (size_t)blockIdx.x * kBlock;
+        const uint32_t to = lrm_opaque(threadIdx.x * 4u);
+        if (i0 < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb0, 3u * to), lrm_at(x + 3 * rb0, 3u * to + 4u), lrm_at(x + 3 * rb0, 3u * to + 8u)}
+                                  : LrmVec3{lrm_at(x + rb0, to), lrm_at(y + rb0, to), lrm_at(z + rb0, to)};
+    }
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(&hd->rows[0]);
+        for (int i = threadIdx.x; i < (int)(sizeof(TabLds) / 16); i += kBlock) reinterpret_cast<uint4*>(&s_tab)[i] = src[i];
+        const uint4* bsrc = reinterpret_cast<const uint4*>(tab + sizeof(LrmTolTabHeader) + 2 * (size_t)hd->bound_off[0]);
+        uint4 v[kTabBoundVecs / kBlock];
+#pragma unroll
+        for (int k = 0; k < kTabBoundVecs / kBlock; k++) v[k] = bsrc[k * kBlock + (int)threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < kTabBoundVecs / kBlock; k++) reinterpret_cast<uint4*>(s_bound)[k * kBlock + (int)threadIdx.x] = v[k];
+        if (threadIdx.x == 0) s_qn = 0;
+        __syncthreads();
+    }
+    const LrmTolTabView G = lrm_toltab_view(tab, s_tab.rows, s_tab.vrows, s_bound, X.r_outer);
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t n_pad = (uint32_t)((n + 63) & ~(size_t)63);
+    const uint32_t n32 = (uint32_t)n;
+    QueueRec* seg = queue + (size_t)blockIdx.x * kTabSegCap;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t toff0 = threadIdx.x * 4u;
+    uint32_t round = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride, round++) {
+        const bool live = i < n32;
+        const size_t rbase = (size_t)blockIdx.x * kBlock + (size_t)round * stride;
+        const uint32_t toff = lrm_opaque(toff0), tid_o = lrm_opaque(threadIdx.x);
+        LrmVec3 p = p_next;
+        {
+            const uint32_t i_next = i + stride;
+            const size_t rb_next = rbase + stride;
+            p_next = LrmVec3{0.f, 0.f, 0.f};
+            if (i_next < n32) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
+                                          : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
+        }
+        uint32_t doubt = 0;
+        const bool m = lrm_xtab_point(lrm_fresh(X), G, p, doubt) && live;
+        doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u;
+        if (live) {
+            if (kAoS) {
+                lrm_at(dx + 3 * rbase, 3u * toff) = p.x;
+                lrm_at(dx + 3 * rbase, 3u * toff + 4u) = p.y;
+                lrm_at(dx + 3 * rbase, 3u * toff + 8u) = p.z;
+            } else {
+                lrm_at(dx + rbase, toff) = p.x;
+                lrm_at(dy + rbase, toff) = p.y;
+                lrm_at(dz + rbase, toff) = p.z;
+            }
+            if (mask) lrm_at(mask + rbase, tid_o) = m;
+        }
+        if (bits) {
+            const uint64_t w = __ballot(m);
+            if (lane == 0) lrm_at(bits + (rbase >> 6), lrm_opaque((uint32_t)wave * 8u)) = w;
+        }
+        const uint64_t dm = __ballot(doubt != 0);
+        if (dm) { // the point is re-loaded by the pushing lanes (it comes back from the L2): three registers fewer in the chain above
+            uint32_t qb = 0;
+            if (lane == 0) qb = atomicAdd(&s_qn, (uint32_t)__popcll(dm));
+            qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+            if (doubt) {
+                const uint32_t qs = qb + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+                if (qs < (uint32_t)kTabSegCap) {
+                    const LrmVec3 q = kAoS ? LrmVec3{lrm_at(x + 3 * rbase, 3u * toff), lrm_at(x + 3 * rbase, 3u * toff + 4u), lrm_at(x + 3 * rbase, 3u * toff + 8u)}
+                                           : LrmVec3{lrm_at(x + rbase, toff), lrm_at(y + rbase, toff), lrm_at(z + rbase, toff)};
+                    seg[qs] = QueueRec{i, q.x, q.y, q.z};
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
 }
 
 // Bit i of the ballot words an earlier launch wrote becomes `m`.  Only this lane ever changes that bit, so a plain
@@ -613,6 +741,156 @@ __global__ __launch_bounds__(kThreads) void tol_fixup_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The fix-up of LRM_MODE_TOL_REL (round 4).  Its queue holds 5 % of a random cloud -- the vectors shorter than
+// lrm_tol_rel_threshold next to the usual 0.5 % of doubtful points -- in per-wave segments (dist_tab_kernel<.., kShort>).
+// Round 3 pushed all of them through tol_fixup_kernel, a latency chain shaped for 4e4 points: +37 us per 1e7 points.  Here
+//   phase B  one lane per record, every thread of the workgroup busy: a record without the "hard" bit runs the table-guided
+//            bit-exact chain (lrm_xtab_point: one yaw candidate, one strict clamp) and stores its result; a hard record, or
+//            one the chain itself doubts, is appended to the workgroup's slow list (LDS);
+//   phase A  the slow list (the 0.5 %) through the filtered code, two lanes per point, exactly as tol_fixup_kernel.
+// One workgroup: kSegs wave segments.  An overflowed segment has all the points of its wave redone by phase A's code.
+// ------------------------------------------------------------------------------------------------------------
+struct KernargRelFix {
+    const float *x, *y, *z;
+    size_t n;
+    LrmCompiledLeg L;
+    LrmXtabLeg X;
+};
+constexpr unsigned kRelFixLegArg = (unsigned)offsetof(KernargRelFix, L), kRelFixXArg = (unsigned)offsetof(KernargRelFix, X);
+#ifndef LRM_REL_FIX_SEGS
+#define LRM_REL_FIX_SEGS 32
+#endif
+template <int kOp, bool kAoS = false, int kSegs = LRM_REL_FIX_SEGS, int kThreads = 256>
+__global__ __launch_bounds__(kThreads) void rel_fixup_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
+    const LrmCompiledLeg L_kernarg, const LrmXtabLeg X_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
+    float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ tab, const QueueRec* __restrict__ queue,
+    const uint32_t* __restrict__ counts, uint32_t nseg, size_t main_stride, uint32_t selftest) {
+    __shared__ FixLds s_tab;
+    __shared__ TabLds s_rows;
+    __shared__ uint32_t s_pre[kSegs + 1], s_cnt[kSegs];
+    __shared__ uint32_t s_slow[kSegs * kWaveSegCap]; // record ordinals of the slow list
+    __shared__ uint32_t s_nslow;
+    static_assert(kSegs <= 64, "one wave scans the counts");
+    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kRelFixLegArg);
+    const LrmXtabLeg& X = lrm_kernarg<LrmXtabLeg>(kRelFixXArg);
+    const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
+    const uint32_t seg0 = blockIdx.x * kSegs;
+    const int tid = threadIdx.x;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(&L.lists[0][0]);
+        const uint4* dsrc = reinterpret_cast<const uint4*>(&L.dist_tab[0][0]);
+        const uint4* csrc = reinterpret_cast<const uint4*>(&L.corner_tab[0]);
+        const uint4* rsrc = reinterpret_cast<const uint4*>(&hd->rows[0]);
+        for (int i = tid; i < (int)(sizeof(s_tab.lists) / 16); i += kThreads) reinterpret_cast<uint4*>(s_tab.lists)[i] = src[i];
+        for (int i = tid; i < (int)(sizeof(s_tab.dist) / 16); i += kThreads) reinterpret_cast<uint4*>(s_tab.dist)[i] = dsrc[i];
+        for (int i = tid; i < (int)(sizeof(s_tab.corners) / 16); i += kThreads) reinterpret_cast<uint4*>(s_tab.corners)[i] = csrc[i];
+        for (int i = tid; i < (int)(sizeof(TabLds) / 16); i += kThreads) reinterpret_cast<uint4*>(&s_rows)[i] = rsrc[i];
+    }
+    if (tid < 64) { // wave 0: the counts and their exclusive prefix (an overflowed segment contributes nothing: it is redone as a whole)
+        const uint32_t c = (tid < kSegs && seg0 + tid < nseg) ? counts[seg0 + tid] : 0u;
+        const uint32_t v = c <= (uint32_t)kWaveSegCap ? c : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+            if (tid >= off) incl += t;
+        }
+        if (tid < kSegs) { s_cnt[tid] = c; s_pre[tid] = incl - v; }
+        if (tid == kSegs - 1) s_pre[kSegs] = incl;
+        if (tid == 0) s_nslow = 0;
+    }
+    __syncthreads();
+    const uint32_t total = s_pre[kSegs];
+    bool any_over = false;
+    for (int j = 0; j < kSegs; j++) any_over = any_over || s_cnt[j] > (uint32_t)kWaveSegCap;
+    if (total == 0 && !any_over) return; // workgroup-uniform
+    const uint32_t* bound_glob = reinterpret_cast<const uint32_t*>(tab + sizeof(LrmTolTabHeader) + 2 * (size_t)hd->bound_off[0]);
+    const LrmTolTabView G = lrm_toltab_view(tab, s_rows.rows, s_rows.vrows, bound_glob, X.r_outer);
+    auto record = [&](uint32_t k) -> QueueRec { // record number k of this workgroup's segments
+        int j = 0;
+#pragma unroll
+        for (int step = kSegs / 2; step >= 1; step >>= 1) j += (s_pre[j + step] <= k) ? step : 0; // kSegs is a power of two
+        return queue[(size_t)(seg0 + j) * kWaveSegCap + (k - s_pre[j])];
+    };
+    static_assert((kSegs & (kSegs - 1)) == 0, "binary search over the prefix");
+    // ---- phase B ----
+    for (uint32_t k0 = 0; k0 < total; k0 += kThreads) { // workgroup-uniform trip count
+        const uint32_t k = k0 + (uint32_t)tid;
+        bool slow = false;
+        if (k < total) {
+            const QueueRec rec = record(k);
+            slow = (rec.i >> 31) != 0u;
+            const size_t i = rec.i & 0x7fffffffu;
+            LrmVec3 p{rec.x, rec.y, rec.z};
+            uint32_t doubt = 0;
+            const bool m = lrm_xtab_point(lrm_fresh(X), G, p, doubt);
+            slow = slow || (doubt & 0xffffu) != 0u || (selftest & 2u) != 0u;
+            if (!slow) {
+                if (kAoS) {
+                    dx[3 * i] = p.x;
+                    dx[3 * i + 1] = p.y;
+                    dx[3 * i + 2] = p.z;
+                } else {
+                    dx[i] = p.x;
+                    dy[i] = p.y;
+                    dz[i] = p.z;
+                }
+                // (mask and bit word: the flag of the tolerance kernel stands -- it is the same decision)
+            }
+        }
+        const uint64_t sm = __ballot(slow);
+        if (sm) {
+            uint32_t base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&s_nslow, (uint32_t)__popcll(sm));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (slow) s_slow[base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u))] = k;
+        }
+    }
+    __syncthreads();
+    // ---- phase A: the filtered code, two lanes per point (see tol_fixup_kernel) ----
+    const LrmDistTables T{s_tab.lists, s_tab.dist, s_tab.corners, (selftest & 2u) ? 1u : 0u};
+    constexpr int kPerPass = kThreads / 2;
+    const int slot = tid >> 1, cand = tid & 1;
+    auto redo = [&](size_t i, LrmVec3 p, bool live) {
+        const bool m = lrm_redo_pair<kOp>(L, T, p, cand);
+        if (live && cand == 0) {
+            if (kAoS) {
+                dx[3 * i] = p.x;
+                dx[3 * i + 1] = p.y;
+                dx[3 * i + 2] = p.z;
+            } else {
+                dx[i] = p.x;
+                dy[i] = p.y;
+                dz[i] = p.z;
+            }
+            if (mask) mask[i] = m;
+            if (bits) patch_bit(bits, i, m);
+        }
+    };
+    const uint32_t nslow = s_nslow;
+    for (uint32_t k0 = 0; k0 < nslow; k0 += kPerPass) { // workgroup-uniform trip count
+        const uint32_t k = k0 + (uint32_t)slot;
+        const bool live = k < nslow;
+        QueueRec rec{0u, 300.f, 0.f, -100.f}; // a lane without a point evaluates a harmless one
+        if (live) rec = record(s_slow[k]);
+        redo((size_t)(rec.i & 0x7fffffffu), LrmVec3{rec.x, rec.y, rec.z}, live);
+    }
+    if (!any_over || main_stride == 0) return;
+    for (int j = 0; j < kSegs; j++) {
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[j]) <= (uint32_t)kWaveSegCap) continue;
+        // every point of wave segment seg0 + j: i = (seg0 + j) * 64 + lane + round * main_stride
+        for (size_t base = (size_t)(seg0 + j) * 64; base < n; base += main_stride) {
+            const size_t i = base + (size_t)slot;
+            const bool live = slot < 64 && i < n;
+            LrmVec3 p{300.f, 0.f, -100.f};
+            if (live) p = kAoS ? LrmVec3{x[3 * i], x[3 * i + 1], x[3 * i + 2]} : LrmVec3{x[i], y[i], z[i]};
+            redo(i, p, live);
+        }
+    }
+}
+
 } // namespace
 
 // LRM_TOL_SELFTEST (tests): bit 0 -- every point is queued (every workgroup's segment overflows: the fix-up re-evaluates the
@@ -680,7 +958,7 @@ static size_t tab_main_blocks(size_t n) {
 size_t lrm_tol_tab_queue_words(size_t n) { return tab_main_blocks(n) * (4 * (size_t)kTabSegCap + 4); }
 size_t lrm_tol_tab_segments(size_t n) { return tab_main_blocks(n); }
 template <int kOp, bool kAoS>
-static hipError_t launch_tab(const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL,
+static hipError_t launch_tab(const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const LrmXtabLeg& X,
                              const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace,
                              uint32_t flags, hipStream_t st) {
     const size_t blocks = tab_main_blocks(n);
@@ -695,10 +973,11 @@ static hipError_t launch_tab(const float* x, const float* y, const float* z, siz
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t stride = blocks * kBlock;
-    if (flags & LRM_TOLF_SHORT) { // several times as many queued points: fewer segments per fix-up workgroup keep it at about one pass
-        const unsigned fblocks = (unsigned)((blocks + LRM_TAB_FIX_SEGS_REL - 1) / LRM_TAB_FIX_SEGS_REL);
-        hipLaunchKernelGGL((tol_fixup_kernel<kOp, kAoS, LRM_TAB_FIX_SEGS_REL, LRM_TAB_FIX_BLOCK_REL>), dim3(fblocks), dim3(LRM_TAB_FIX_BLOCK_REL), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts,
-                           (uint32_t)blocks, (uint32_t)kTabSegCap, stride, flags | tol_selftest_env());
+    if (flags & LRM_TOLF_SHORT) { // per-wave segments: throughput pass + the filtered code for the slow list (rel_fixup_kernel)
+        const size_t nseg = blocks * (kBlock / 64);
+        const unsigned fblocks = (unsigned)((nseg + LRM_REL_FIX_SEGS - 1) / LRM_REL_FIX_SEGS);
+        hipLaunchKernelGGL((rel_fixup_kernel<kOp, kAoS>), dim3(fblocks), dim3(256), 0, st, x, y, z, n, L, X, mask, bits, dx, dy, dz, tab_dev, queue, counts,
+                           (uint32_t)nseg, stride, flags | tol_selftest_env());
     } else {
         const unsigned fblocks = (unsigned)((blocks + LRM_TAB_FIX_SEGS - 1) / LRM_TAB_FIX_SEGS);
         hipLaunchKernelGGL((tol_fixup_kernel<kOp, kAoS, LRM_TAB_FIX_SEGS>), dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts,
@@ -707,15 +986,42 @@ static hipError_t launch_tab(const float* x, const float* y, const float* z, siz
     return hipGetLastError();
 }
 hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
-                               const LrmTolLeg& TL, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
+                               const LrmTolLeg& TL, const LrmXtabLeg& X, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
                                float* dz, uint32_t* workspace /* lrm_tol_tab_queue_words(n) uint32 */, uint32_t flags, hipStream_t st) {
-    return op == 2 ? launch_tab<2, false>(x, y, z, n, L, TL, tab_dev, mask, bits, dx, dy, dz, workspace, flags, st)
-                   : launch_tab<1, false>(x, y, z, n, L, TL, tab_dev, mask, bits, dx, dy, dz, workspace, flags, st);
+    return op == 2 ? launch_tab<2, false>(x, y, z, n, L, TL, X, tab_dev, mask, bits, dx, dy, dz, workspace, flags, st)
+                   : launch_tab<1, false>(x, y, z, n, L, TL, X, tab_dev, mask, bits, dx, dy, dz, workspace, flags, st);
 }
-hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const uint8_t* tab_dev,
+hipError_t lrm_launch_dist_tab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const LrmXtabLeg& X, const uint8_t* tab_dev,
                                    uint8_t* mask, float* dxyz, uint32_t* workspace, uint32_t flags, hipStream_t st) {
-    return op == 2 ? launch_tab<2, true>(xyz, nullptr, nullptr, n, L, TL, tab_dev, mask, nullptr, dxyz, nullptr, nullptr, workspace, flags, st)
-                   : launch_tab<1, true>(xyz, nullptr, nullptr, n, L, TL, tab_dev, mask, nullptr, dxyz, nullptr, nullptr, workspace, flags, st);
+    return op == 2 ? launch_tab<2, true>(xyz, nullptr, nullptr, n, L, TL, X, tab_dev, mask, nullptr, dxyz, nullptr, nullptr, workspace, flags, st)
+                   : launch_tab<1, true>(xyz, nullptr, nullptr, n, L, TL, X, tab_dev, mask, nullptr, dxyz, nullptr, nullptr, workspace, flags, st);
+}
+
+// LRM_MODE_FAST through the table: dist_xtab_kernel + tol_fixup_kernel for its doubtful points.  Workspace as lrm_launch_dist_tab.
+template <int kOp, bool kAoS>
+static hipError_t launch_xtab(const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L, const LrmXtabLeg& X,
+                              const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace, hipStream_t st) {
+    const size_t blocks = tab_main_blocks(n);
+    uint32_t* counts = workspace;
+    QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks);
+    hipLaunchKernelGGL((dist_xtab_kernel<kOp, kAoS>), dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, X, mask, bits, dx, dy, dz, tab_dev, queue, counts, tol_selftest_env());
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t stride = blocks * kBlock;
+    const unsigned fblocks = (unsigned)((blocks + LRM_TAB_FIX_SEGS - 1) / LRM_TAB_FIX_SEGS);
+    hipLaunchKernelGGL((tol_fixup_kernel<kOp, kAoS, LRM_TAB_FIX_SEGS>), dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts,
+                       (uint32_t)blocks, (uint32_t)kTabSegCap, stride, tol_selftest_env());
+    return hipGetLastError();
+}
+hipError_t lrm_launch_dist_xtab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L, const LrmXtabLeg& X,
+                                const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace, hipStream_t st) {
+    return op == 2 ? launch_xtab<2, false>(x, y, z, n, L, X, tab_dev, mask, bits, dx, dy, dz, workspace, st)
+                   : launch_xtab<1, false>(x, y, z, n, L, X, tab_dev, mask, bits, dx, dy, dz, workspace, st);
+}
+hipError_t lrm_launch_dist_xtab_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmXtabLeg& X, const uint8_t* tab_dev,
+                                    uint8_t* mask, float* dxyz, uint32_t* workspace, hipStream_t st) {
+    return op == 2 ? launch_xtab<2, true>(xyz, nullptr, nullptr, n, L, X, tab_dev, mask, nullptr, dxyz, nullptr, nullptr, workspace, st)
+                   : launch_xtab<1, true>(xyz, nullptr, nullptr, n, L, X, tab_dev, mask, nullptr, dxyz, nullptr, nullptr, workspace, st);
 }
 
 // The same two launches on the float3 arrays of the apply_kernel boundary (cross_compiled.cu:33-79): no bit words.

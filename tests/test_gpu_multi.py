@@ -61,3 +61,26 @@ def test_multi_argument_errors(lrm):
         lrm.apply_reach_dist_multi(pts, leg, None, ndev=1, devices=[ndev])      # ordinal out of range
     with pytest.raises(lrm.LrmError):
         lrm.apply_reach_dist_multi(pts, leg, None, ndev=ndev + 1)               # more devices than the box has
+
+
+@pytest.mark.parametrize("mode", ["tol", "tol_rel", "fast"])
+def test_multi_calls_do_not_leak_queue_workspaces(lrm, mode):
+    """lrm_reach_dist_multi creates and destroys a stream per device and call; the table-guided modes key their queue workspace by
+    (device, stream): the entry must go with the stream (round 3 kept one 60 MB workspace per call for ever)."""
+    import torch
+    pts = random_cloud(2_000_000, seed=12)
+    leg = lrm.get_M2_leg(0.0)
+    lrm.set_mode({"tol": lrm.MODE_TOL, "tol_rel": lrm.MODE_TOL_REL, "fast": lrm.MODE_FAST}[mode])
+    try:
+        for _ in range(2):
+            lrm.apply_reach_dist_multi(pts, leg, None, ndev=1)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        for _ in range(12):
+            lrm.apply_reach_dist_multi(pts, leg, None, ndev=1)
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+    finally:
+        lrm.set_mode(lrm.MODE_FAST)
+        lrm.lib().lrm_multi_release()
+    assert free0 - free1 < (16 << 20), f"{(free0 - free1) >> 20} MiB of device memory went missing over 12 calls"

@@ -12,10 +12,19 @@ from conftest import bits_equal, golden_cases, load_case, random_cloud
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["strict", "fast"])
-def mode(request, lrm):
-    """Every GPU test runs in both arithmetic modes; both must be bit-identical to the oracle."""
-    lrm.set_mode(lrm.MODE_FAST if request.param == "fast" else lrm.MODE_STRICT)
+@pytest.fixture(autouse=True, params=["strict", "fast", "fast_table", "fast_filtered"])
+def mode(request, lrm, monkeypatch):
+    """Every GPU test runs in the bit-exact arithmetic modes; all must be bit-identical to the oracle.
+      strict         lrm_point.h verbatim
+      fast           the library default: the table-guided kernel (dist_xtab_kernel, lrm_point_xtab.h) from 2e5 points on,
+                     the filtered kernel (dist_soa_kernel<., true>, lrm_point_fast.h) below and for legs without a table
+      fast_table     LRM_TOL_TABLE=2: the table-guided kernel whatever the size (every fixture, every ragged size)
+      fast_filtered  LRM_XTAB=0: the filtered kernel whatever the size (what rounds 1-3 shipped; still the fallback)"""
+    lrm.set_mode(lrm.MODE_STRICT if request.param == "strict" else lrm.MODE_FAST)
+    if request.param == "fast_table":
+        monkeypatch.setenv("LRM_TOL_TABLE", "2")
+    if request.param == "fast_filtered":
+        monkeypatch.setenv("LRM_XTAB", "0")
     yield request.param
     lrm.set_mode(lrm.MODE_FAST)  # the library default
 
@@ -121,10 +130,12 @@ def test_random_cloud_1e6_all_legs_and_orientations(lrm, oracle, torch_cuda):
             assert bits_equal(d.cpu().numpy().T, want_d).all()
 
 
-def test_full_size_config2_1e7_points(lrm, oracle, torch_cuda):
+def test_full_size_config2_1e7_points(lrm, oracle, torch_cuda, mode):
     """BASELINE config 2 at full size: 1e7 random targets, M2 leg, identity orientation.
     The oracle is run on the whole cloud for the mask (~1 s) and on a 2e6 slice for the
     distance field; the rest of the field is covered by properties."""
+    if mode == "fast_table":
+        pytest.skip("at this size the default dispatch already runs the table-guided kernel")
     n = 10_000_000
     pts = random_cloud(n, seed=42)
     leg = lrm.get_M2_leg(0.0)
@@ -282,7 +293,7 @@ def test_config4_cloud_1e8_points_on_one_gpu(lrm, oracle, torch_cuda, mode):
     eighth of it): reach mask + bit words, checked exactly against the oracle on three 1e6-point
     windows and through size-independent properties everywhere (bytes are 0/1, bit words unpack to
     the bytes, popcount = byte sum, a shifted window of the same points gives the same answers)."""
-    if mode == "strict":
+    if mode != "fast":
         pytest.skip("the 1e8-point run is done once, in the default mode")
     n = 100_000_000
     rng = np.random.default_rng(4)
