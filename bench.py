@@ -16,12 +16,13 @@ bit words + 3-component distance field) over a synthetic cloud that is already r
           the fused launch on the shard + the RCCL all-gather of the bit-packed reach mask (side stream,
           overlapping the next step's kernel).  Strong scaling: the total work is fixed.
 
-The headline runs in LRM_MODE_TOL: reach mask bit-exact, distance field within 1e-5 of max(|d|, (|p| + body)/8) -- a
-floored reading of BASELINE.json's "within 1e-5 relative" (frozen in include/lrm.h and tests/tolcheck.py; literally
-relative for every vector longer than 1/8 of the coordinate scale, an absolute ~1e-3 mm bound below).  The line
-carries the error statistics of the very output it timed ("tolerance_check", literal relative error included).
-The bit-exact mode (LRM_MODE_FAST: every float of the distance field identical to the reference's host path -- it
-meets the north star literally) is timed next to it and reported under "modes" with its own roofline fraction.
+The headline runs in LRM_MODE_TOL_REL, the literal text of BASELINE.json: reach mask bit-exact and |d - d_ref| <= 1e-5 |d_ref|
+for EVERY distance vector (vectors shorter than max(17 mm, 2000 decision bands) come from the table-guided bit-exact chain of
+csrc/lrm_point_xtab.h, all others from the tolerance arithmetic).  The line carries the error statistics of the very output
+it timed ("tolerance_check").  Timed next to it and reported under "modes" with their own roofline fractions:
+LRM_MODE_FAST (every float of the distance field identical to the reference's host path: tolerance 0; since round 4 the
+table-guided kernel), the filtered kernel it replaced (LRM_XTAB=0), and LRM_MODE_TOL (a FLOORED reading of the tolerance:
+faster, and NOT the contract).
 value = leg-target evaluations per second over the whole job, one evaluation = reachability AND distance vector
 of one (leg, target) pair.  Rank 0 prints ONE JSON line.
 """
@@ -105,7 +106,8 @@ def cpu_baseline(sample_points, leg):
     Primary: the product's own CPU entry points lrm_reach_cpu + lrm_dist_cpu (the apply_reach_cpu / apply_dist_cpu
     drop-ins, cross_compiled.cu:163-181; bit-identical to the reference's host path), one thread as the reference
     runs them and all cores with a static split.  Beside it: the RBDL-equivalent LM position IK (apply_RBDL's work,
-    parity unpinned) and, where the git-ignored oracle/_ref/libref.so exists, the reference's own host build."""
+    parity unpinned).  (The reference's own host build, oracle/_ref/libref.so, no longer travels to the GPU box: its single-thread
+    rate in the build container is recorded in DESIGN.md section 5.)"""
     from concurrent.futures import ThreadPoolExecutor
     import lrm_amd
     pts = np.ascontiguousarray(sample_points.T)  # AoS, as the reference's Array<float3>
@@ -147,18 +149,6 @@ def cpu_baseline(sample_points, leg):
         "note": "RBDL-equivalent Levenberg-Marquardt position IK (same chain incl. /400, max_steps 10, <= 5 starts) with "
                 "closed-form kinematics; RBDL itself is an external unpinned dependency that is absent: parity unpinned, "
                 "timing baseline only; published RBDL figure: 14 610 ns/point on an i5-12600K (bdata/pc/rbdl.csv)"}
-    try:
-        from oracle import orc
-        if orc.ref_available():
-            ref = orc.Ref()
-            t0 = time.perf_counter()
-            ref.reach(pts[:n1], leg)
-            ref.dist(pts[:n1], leg)
-            out["reference_host_path"] = {"single_thread_value": n1 / (time.perf_counter() - t0),
-                                          "note": "oracle/_ref/libref.so: the reference's own host sources compiled in the "
-                                                  "build container (git-ignored; absent from a fresh clone)"}
-    except Exception:  # the checker is optional here
-        pass
     return out
 
 
@@ -218,6 +208,60 @@ def config3_block(torch, lrm_amd):
     return block
 
 
+def cache_and_scaling_block(torch, lrm_amd, leg, cloud, mask, field, time_kernel):
+    """What the headline figure owes to the 256 MiB Infinity Cache, and the two ends of the curve `--gpus N` draws -- all in
+    the headline's mode, on one GPU, outside the timed region:
+      copy_soa            the box's achieved copy bandwidth: a (3, n) float32 tensor copied device to device (read + write)
+      fused_rotating      the config-2 step over FOUR distinct 1e7-point clouds round-robin, each with its own outputs: 1 GB is
+                          touched between two uses of a buffer, so nothing a step reads or writes is still in the cache
+      fused_shard_1.25e7  one GPU's share of the 1e8-point cloud at N = 8
+      fused_1e8_one_gpu   the whole 1e8-point cloud on one GPU (the base of the strong-scaling curve)"""
+    n = cloud.shape[1]
+    out = {}
+    dst = torch.empty_like(cloud)
+    ms = time_kernel(lambda: dst.copy_(cloud), reps=200)
+    copy_gbs = 2 * cloud.numel() * 4 / (ms * 1e-3) / 1e9
+    out["copy_soa"] = {"ms": ms, "GBs": copy_gbs, "bytes": 2 * cloud.numel() * 4,
+                       "what": f"torch device-to-device copy of the (3, {n}) float32 cloud, read + write bytes over HIP-event time"}
+    del dst
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    lo_t, span = torch.tensor(LO, device="cuda").view(3, 1), torch.tensor(HI - LO, device="cuda").view(3, 1)
+
+    def rand_cloud(m):
+        return (torch.rand((3, m), device="cuda", generator=g) * span + lo_t).contiguous()
+
+    def fused(c, m_, f_, w_):
+        lrm_amd.device.reach_dist(c[0], c[1], c[2], leg, None, mask=m_, out=f_, bits=w_)
+
+    sets = []
+    for _ in range(4):
+        sets.append((rand_cloud(n), torch.empty(n, dtype=torch.uint8, device="cuda"), torch.empty((3, n), dtype=torch.float32, device="cuda"),
+                     torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")))
+    state = {"k": 0}
+
+    def rot():
+        c, m_, f_, w_ = sets[state["k"] & 3]
+        state["k"] += 1
+        fused(c, m_, f_, w_)
+
+    ms = time_kernel(rot, reps=200)
+    out["fused_rotating"] = {"kernel_ms": ms, "roofline_frac": BYTES_PER_EVAL["reach_dist"] * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "ps_per_point": ms * 1e9 / n,
+                             "what": "four distinct clouds of the config-2 size with their own outputs, round-robin: 1 GB touched between two uses of any buffer"}
+    del sets
+    for key, m in (("fused_shard_1.25e7", 12_500_000), ("fused_1e8_one_gpu", 100_000_000)):
+        c = rand_cloud(m)
+        m_, f_ = torch.empty(m, dtype=torch.uint8, device="cuda"), torch.empty((3, m), dtype=torch.float32, device="cuda")
+        w_ = torch.empty((m + 63) // 64, dtype=torch.int64, device="cuda")
+        ms = time_kernel(lambda: fused(c, m_, f_, w_), reps=50 if m > 20_000_000 else 200)
+        out[key] = {"points": m, "kernel_ms": ms, "ps_per_point": ms * 1e9 / m,
+                    "roofline_frac": BYTES_PER_EVAL["reach_dist"] * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del c, m_, f_, w_
+    torch.cuda.empty_cache()
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,7 +270,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--points", type=int, default=None, help="N = 1: targets of the config-2 cloud (default 1e7)")
     ap.add_argument("--total-points", type=int, default=100_000_000, help="N > 1: points of the one sharded cloud")
-    ap.add_argument("--mode", choices=["tol", "tol_rel", "fast", "strict"], default="tol", help="arithmetic mode of the headline")
+    ap.add_argument("--mode", choices=["tol", "tol_rel", "fast", "strict"], default="tol_rel", help="arithmetic mode of the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed secondary figures (other mode, reach/dist only, brackets, config 3)")
     ap.add_argument("--no-tolerance-check", action="store_true", help="skip the untimed comparison of the timed output with lrm_dist_cpu")
@@ -465,6 +509,14 @@ def main():
     def compute(words, lo, hi):
         lrm_amd.device.reach_dist(x, y, z, leg, None, mask=mask[:n], out=field[:, :n], bits=words)
 
+    # the plane table of this (leg, orientation) is built by the first call: timed here, cold, outside the steps
+    lrm_amd.release_workspaces()
+    torch.cuda.synchronize()
+    t_tab = time.perf_counter()
+    lrm_amd.tol_prepare(leg, None, n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    table_build_ms = {"first_call_prepare_ms": (time.perf_counter() - t_tab) * 1e3, "table_ms": lrm_amd.last_table_build_ms()}
+
     def full_sync():
         torch.cuda.synchronize()
         if world > 1:
@@ -555,18 +607,22 @@ def main():
     extra, other_modes, configs = {}, {}, {}
     if rank == 0 and not args.no_extras:
         words = loop.words[0][:loop.local_words]
-        for name in ("tol", "tol_rel", "fast"):  # the other arithmetic modes, same launch, untimed region
+        contracts = {
+            "fast": "meets north_star at tolerance 0: reach mask AND every float of the distance field bit-identical to the reference's host "
+                    "path (since round 4 the table-guided kernel dist_xtab_kernel + the filtered fix-up of its doubtful points)",
+            "fast_filtered": "as fast, by the filtered kernel of rounds 1-3 (LRM_XTAB=0; still what small clouds and legs without a table run)",
+            "tol_rel": "meets north_star literally: reach mask bit-identical, |d - d_ref| <= 1e-5 |d_ref| for every vector",
+            "tol": "NOT the contract: reach mask bit-identical, distance within 1e-5 of max(|d|, (|p| + body)/8) -- a floored reading",
+        }
+        for name in ("tol_rel", "fast", "fast_filtered", "tol"):  # the other arithmetic modes, same launch, untimed region
             if name == args.mode:
                 continue
-            lrm_amd.set_mode(modes[name])
-            ms = time_kernel(lambda: compute(words, loop.lo, loop.hi), reps=200)
-            other_modes[name] = {"kernel_ms": ms, "evals_per_s_per_gpu": n / (ms * 1e-3), "roofline_frac": frac_of(ms)}
-            if name == "fast":
-                other_modes[name]["contract"] = ("meets north_star literally: reach mask AND every float of the distance field "
-                                                 "bit-identical to the reference's host path (tolerance 0)")
-            if name == "tol_rel":
-                other_modes[name]["contract"] = ("meets north_star literally: reach mask bit-identical, |d - d_ref| <= 1e-5 |d_ref| for every vector "
-                                                 "(those shorter than 17 mm come from the bit-exact code, the others from the tolerance arithmetic)")
+            lrm_amd.set_mode(modes["fast" if name == "fast_filtered" else name])
+            if name == "fast_filtered":
+                os.environ["LRM_XTAB"] = "0"
+            try:
+                ms = time_kernel(lambda: compute(words, loop.lo, loop.hi), reps=200)
+                other_modes[name] = {"kernel_ms": ms, "evals_per_s_per_gpu": n / (ms * 1e-3), "roofline_frac": frac_of(ms), "contract": contracts[name]}
                 if world == 1 and not args.no_tolerance_check:  # the output this mode just left behind
                     c = tolerance_check(lrm_amd, host, leg, mask, field)
                     other_modes[name]["tolerance_check"] = {k: c[k] for k in ("points", "mask_mismatches", "bit_identical_vectors", "max_plain_rel",
@@ -576,6 +632,8 @@ def main():
                         other_modes[name]["queued_fraction"] = nq / max(npts, 1)
                     except lrm_amd.LrmError:
                         pass
+            finally:
+                os.environ.pop("LRM_XTAB", None)
         lrm_amd.set_mode(modes[args.mode])
         ms_reach = time_kernel(lambda: lrm_amd.device.reach(x, y, z, leg, out=mask[:n], bits=words))
         valid = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -594,13 +652,14 @@ def main():
             del valid
             for bname, c in bracket_clouds(torch, lrm_amd, n, leg).items():
                 row = {}
-                for name in ("tol", "fast"):
+                for name in ("tol_rel", "fast"):
                     lrm_amd.set_mode(modes[name])
                     ms = time_kernel(lambda: lrm_amd.device.reach_dist(c[0], c[1], c[2], leg, None, mask=mask[:n], out=field[:, :n], bits=words), reps=200)
                     row[name] = {"kernel_ms": ms, "roofline_frac": frac_of(ms)}
                 extra["fused_" + bname] = row
                 del c
             lrm_amd.set_mode(modes[args.mode])
+            extra.update(cache_and_scaling_block(torch, lrm_amd, leg, cloud, mask, field, time_kernel))
             configs["c3_positionability"] = config3_block(torch, lrm_amd)
     if world > 1:
         dist.barrier()
@@ -609,8 +668,9 @@ def main():
         total_evals = float(n_total) * args.steps
         achieved = BYTES_PER_EVAL["reach_dist"] * n / (kernel_ms * 1e-3) / 1e9
         kname = {"tol": "dist_tab_kernel<2, false, false> + tol_fixup_kernel<2, false, 8, 128> (one step = both launches)",
-                 "tol_rel": "dist_tab_kernel<2, false, true> + tol_fixup_kernel<2, false, 8, 256> (one step = both launches)",
-                 "fast": "dist_soa_kernel<2, true>", "strict": "dist_soa_kernel<2, false>"}[args.mode]
+                 "tol_rel": "dist_tab_kernel<2, false, true> + rel_fixup_kernel<2, false, 32, 256> (one step = both launches)",
+                 "fast": "dist_xtab_kernel<2, false> + tol_fixup_kernel<2, false, 8, 128> (one step = both launches)",
+                 "strict": "dist_soa_kernel<2, false>"}[args.mode]
         prof = committed_profile(n, args.mode)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -623,6 +683,9 @@ def main():
             "kernel_src_sha": prof["kernel_src_sha"],
             "valu_insts_per_eval": prof["valu_insts_per_eval"], "valu_source": prof["valu_source"],
         }
+        if extra.get("copy_soa"):
+            roofline["measured_copy_GBs"] = extra["copy_soa"]["GBs"]
+            roofline["frac_of_measured_copy"] = achieved / extra["copy_soa"]["GBs"]
         if prof["valu_insts_per_eval"]:
             # the kernel is VALU-issue bound: its own floor = wave-instructions / SIMDs x 2 cycles (full-rate class)
             floor_ms = prof["valu_insts_per_eval"] * n / 64.0 / N_SIMD * 2.0 / CLOCK_HZ * 1e3
@@ -649,11 +712,14 @@ def main():
                             (f"BASELINE config 4: single M2 leg, reach+distance on ONE cloud of {n_total} uniform-random 3-D targets "
                              f"(chunk-seeded), sharded contiguously over {world} GPUs ({n} points on rank 0), SoA resident in HBM"),
                 "points_total": n_total, "points_per_gpu": n, "mode": args.mode,
+                "table_build_ms": table_build_ms,
+                "table_build_note": "the plane table of this (leg, orientation): built once, on the first call, before the timed region "
+                                    "(lrm_tol_prepare); its cost is this figure, per (leg, orientation), not per step",
                 "mode_contract": {"tol": "reach mask bit-exact; distance within 1e-5 of max(|d|, (|p| + body)/8): a FLOORED reading of "
                                          "BASELINE's '1e-5 relative' (include/lrm.h; literal relative error in tolerance_check)",
                                   "tol_rel": "reach mask bit-exact; |d - d_ref| <= 1e-5 |d_ref| for every vector (BASELINE's text without a floor: vectors "
                                              "shorter than 17 mm come from the bit-exact code)",
-                                  "fast": "mask and every float of the distance field bit-identical to the reference's host path",
+                                  "fast": "mask and every float of the distance field bit-identical to the reference's host path (table-guided kernel)",
                                   "strict": "as fast, reference operation order"}[args.mode],
                 "exchange": "none" if world == 1 else f"{'RCCL' if backend == 'nccl' else backend} all-gather of the "
                                                          "bit-packed reach mask per step, overlapped on a side stream",

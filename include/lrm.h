@@ -168,6 +168,10 @@ int lrm_rbdl_equiv_cpu(const float* xyz_aos, size_t n, const LrmLegDimensions* l
  * recently used out.  lrm_release_workspaces frees every cached device buffer (queues, tables, the host pipeline's
  * buffers and streams, the multi-device communicators); the next call re-creates what it needs. */
 int lrm_tol_prepare(const LrmLegDimensions* leg, const float* quat, size_t n_max, void* stream);
+/* Milliseconds the most recent plane-table build of this process took (the table of a (leg, orientation) is built by the first
+ * call that needs it, or by lrm_tol_prepare, and cached); -1 when none has been built yet.  bench.py reports it as
+ * config.table_build_ms next to ms_per_step. */
+int lrm_tol_table_build_ms(float* ms_out);
 void lrm_release_workspaces(void);
 int lrm_reach_dev(const float* x, const float* y, const float* z, size_t n,
                   const LrmLegDimensions* leg, const float* quat, uint8_t* mask, void* stream);
@@ -355,6 +359,11 @@ int lrm_dbg_toltab_host(const float* xyz_aos, size_t n, const LrmLegDimensions* 
  * second value chain ran, table bytes. */
 int lrm_dbg_xtab_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                       uint8_t* mask_out, float* dxyz_out, uint32_t* doubt_out, uint32_t* stats_out);
+/* LRM_MODE_TOL_REL's two steps on the host: the tolerance evaluation with the plane table, then -- for every point without doubt --
+ * the strict replay of the winner's value chain from the decisions the first step took (csrc/lrm_point_xtab.h: lrm_xtab_replay):
+ * those vectors equal lrm_dist_cpu bit for bit (tests/test_xtab_cpu.py).  A point in doubt keeps the tolerance vector. */
+int lrm_dbg_replay_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
+                        uint8_t* mask_out, float* dxyz_out, uint32_t* doubt_out);
 /* The plane table's lower bound of the in-plane distance at n plane points xz[2 n] (abscissa - coxa_length, z), next to the
  * full plane evaluation there: distance sqrt(du^2 + dz^2), validity, doubt bits.  The bound must not exceed the distance
  * of an invalid point and must be 0 at a valid one (tests/test_tol_cpu.py). */

@@ -85,9 +85,11 @@ def load():
         "lrm_dbg_toltab_host": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_toltab_bounds": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_xtab_host": [vp, sz, vp, vp, vp, vp, vp, vp],
+        "lrm_dbg_replay_host": [vp, sz, vp, vp, vp, vp, vp],
         "lrm_shard_bounds": [sz, C.c_int, C.c_int, sz, vp, vp],
         "lrm_dbg_pair_counts": [vp],
         "lrm_tol_prepare": [vp, vp, sz, vp],
+        "lrm_tol_table_build_ms": [vp],
         "lrm_positionability_dev": [vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, sz, C.c_int, vp, vp, vp],
         "lrm_dbg_oct_trace": [C.c_int],
         "lrm_dbg_oct_trace_read": [vp, sz, vp],
@@ -233,6 +235,13 @@ def apply_reach_dist(xyz, leg, quat=None):
 def tol_prepare(leg, quat=None, n_max=0, stream=None):
     """lrm_tol_prepare: LRM_MODE_TOL's tables and queues for (leg, orientation) and clouds of up to n_max points, ahead of time"""
     check(load().lrm_tol_prepare(_ptr(_f32(leg, (14,))), _ptr(_quat(quat)), n_max, stream))
+
+
+def last_table_build_ms():
+    """milliseconds the most recent plane-table build took (-1.0: none yet)"""
+    ms = C.c_float(0)
+    check(load().lrm_tol_table_build_ms(C.byref(ms)))
+    return float(ms.value)
 
 
 def release_workspaces():
@@ -444,6 +453,16 @@ def dbg_xtab_host(xyz, leg, quat=None):
     check(load().lrm_dbg_xtab_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d),
                                    _ptr(doubt), _ptr(stats)))
     return mask, d, doubt, dict(second_chains=int(stats[0]), bytes=int(stats[1]))
+
+
+def dbg_replay_host(xyz, leg, quat=None):
+    """the tolerance evaluation with the plane table + the strict replay of its decisions (LRM_MODE_TOL_REL's short-vector path)
+    on the host -> (mask, vectors, doubt bits); vectors of points without doubt are the bit-exact ones"""
+    xyz = _f32(xyz, (-1, 3))
+    n = len(xyz)
+    mask, d, doubt = np.zeros(n, np.uint8), np.zeros_like(xyz), np.zeros(n, np.uint32)
+    check(load().lrm_dbg_replay_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d), _ptr(doubt)))
+    return mask, d, doubt
 
 
 def dbg_toltab_bounds(xz, leg, quat=None):

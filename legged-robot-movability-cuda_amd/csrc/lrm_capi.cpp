@@ -229,8 +229,7 @@ int launch_dist_any(int op, const float* xyz_aos, const float* x, const float* y
                 int dev = 0;
                 (void)hipGetDevice(&dev);
                 // the workspace starts with one count per segment
-                if (tab && mode == LRM_MODE_TOL_REL) g_tol_last = TolLast{dev, w, lrm_tol_tab_segments(n) * 4, n, (uint32_t)LRM_TOL_TAB_SEG_CAP / 4};
-                else if (tab) g_tol_last = TolLast{dev, w, lrm_tol_tab_segments(n), n, (uint32_t)LRM_TOL_TAB_SEG_CAP};
+                if (tab) g_tol_last = TolLast{dev, w, lrm_tol_tab_segments(n), n, (uint32_t)LRM_TOL_TAB_SEG_CAP};
                 else g_tol_last = TolLast{dev, w, lrm_tol_queue_words(n) / (4 * LRM_TOL_SEG_CAP_WORDS + 4), n, (uint32_t)LRM_TOL_SEG_CAP_WORDS};
                 return LRM_OK;
             }
@@ -1121,6 +1120,39 @@ int lrm_dbg_xtab_host(const float* xyz, size_t n, const LrmLegDimensions* leg, c
     }
     return LRM_OK;
 }
+// LRM_MODE_TOL_REL's two steps on the host: the tolerance evaluation with the plane table (lrm_tab_point<true>: mask, doubt bits and
+// the DECISIONS it took), then the strict replay of the winner's value chain from those decisions (lrm_xtab_replay) for every point
+// without doubt: dxyz_out must then equal lrm_dist_cpu bit for bit (tests/test_xtab_cpu.py).
+int lrm_dbg_replay_host(const float* xyz, size_t n, const LrmLegDimensions* leg, const float* quat, uint8_t* mask_out,
+                        float* dxyz_out, uint32_t* doubt_out) {
+    if (!leg || (n && (!xyz || !mask_out || !dxyz_out || !doubt_out))) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    LrmTolLeg TL;
+    lrm_compile_tol(L, &TL);
+    if (!TL.tol_ok) return fail(LRM_EINVAL, "leg not eligible for the table-guided modes");
+    std::vector<uint8_t> tab;
+    if (!lrm_build_tol_tab(TL, &tab)) return fail(LRM_EINVAL, "leg needs more table rows than a cell code can name");
+    const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab.data());
+    const LrmTolTabView G = lrm_toltab_view(tab.data(), hd->rows, hd->vrows, lrm_toltab_bound_inner(tab.data()), TL.r_outer);
+    LrmXtabLeg X;
+    lrm_make_xtab_leg(L, TL, &X);
+    for (size_t i = 0; i < n; i++) {
+        const LrmVec3 p_in{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        LrmVec3 p = p_in;
+        uint32_t doubt = 0, info = 0;
+        mask_out[i] = lrm_tab_point<true>(TL, G, p, doubt, &info);
+        if ((doubt & 0xffffu) == 0u) {
+            p = p_in;
+            lrm_xtab_replay(X, hd->rows, p, info);
+        }
+        dxyz_out[3 * i] = p.x;
+        dxyz_out[3 * i + 1] = p.y;
+        dxyz_out[3 * i + 2] = p.z;
+        doubt_out[i] = doubt;
+    }
+    return LRM_OK;
+}
 // The table's lower bound of the in-plane distance at plane points (x = abscissa - coxa_length, z) of the INNER grid, next
 // to what the full plane evaluation (lrm_tol_plane) finds there: tests/test_tol_cpu.py checks bound <= distance.
 int lrm_dbg_toltab_bounds(const float* xz, size_t n, const LrmLegDimensions* leg, const float* quat, float* lb_out,
@@ -1531,6 +1563,14 @@ int lrm_tol_prepare(const LrmLegDimensions* leg, const float* quat, size_t n_max
     }
     uint32_t* w = nullptr;
     return tol_workspace(std::max(lrm_tol_tab_queue_words(n_max), lrm_tol_queue_words(n_max)), stream, &w);
+}
+
+// milliseconds the most recent plane-table build of this process took (host wall clock around the builder; -1: none yet)
+int lrm_tol_table_build_ms(float* ms_out) {
+    if (!ms_out) return fail(LRM_EINVAL, "null argument");
+    std::lock_guard<std::recursive_mutex> g(g_cache_mu);
+    *ms_out = g_last_tab_build_ms;
+    return LRM_OK;
 }
 
 void lrm_release_workspaces(void) {

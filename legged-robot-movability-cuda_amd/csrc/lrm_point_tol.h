@@ -333,6 +333,14 @@ LRM_HD void lrm_toltab_lookup2(const LrmTolTabView& G, bool far, float band, flo
         p0 = fminf(fmaxf(p0, 0.f), kMaxS);
         p1 = fminf(fmaxf(p1, 0.f), kMaxS);
     }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // host: a nan position (the coxa origin itself: r = 0 * inf) converts to INT_MIN on x86 where v_cvt_i32_f32 gives 0; the
+    // point is in doubt either way, the look-up must only stay inside the table
+    if (!(pz == pz)) pz = 0.f;
+    if (!(p0 == p0)) p0 = 0.f;
+    if (!(p1 == p1)) p1 = 0.f;
+    if (!kMixed) { pz = fminf(fmaxf(pz, 0.f), kMaxS); p0 = fminf(fmaxf(p0, 0.f), kMaxS); p1 = fminf(fmaxf(p1, 0.f), kMaxS); }
+#endif
     const uint32_t qz = (uint32_t)(int)pz, q0 = (uint32_t)(int)p0, q1 = (uint32_t)(int)p1; // >= 0: truncation is floor
     static_assert(LRM_TT_SUB == 16, "shifts below");
     const uint32_t row = (qz >> 4) * (uint32_t)LRM_TT_N;
@@ -379,8 +387,10 @@ LRM_HD uint32_t lrm_toltab_resolve(const LrmTolTabView& G, uint32_t c, uint32_t 
 }
 // lrm_tol_plane restricted to what the cell's code names: at most two clamp targets, one circle's point validity.
 // Same arithmetic as lrm_tol_plane on those operands.  x = abscissa - coxa_length.
+// kInfo: also report which of the cell's two rows won (`row`), for the queue records of LRM_MODE_TOL_REL.
+template <bool kInfo = false>
 LRM_HD void lrm_tol_plane_tab(const LrmTolTabView& G, uint32_t code, float x, float z, float band, float tau,
-                              float& du, float& dz, bool& valid, uint32_t& doubt) {
+                              float& du, float& dz, bool& valid, uint32_t& doubt, uint32_t* row = nullptr) {
 #if defined(LRM_TAB_EXP_ONE_ROW) && defined(__HIP_DEVICE_COMPILE__) // timing experiment (wrong results): every lane reads the same rows -- no LDS bank conflicts
     uint32_t code_rows = code;
     asm volatile("v_and_b32 %0, 0x421, %0" : "+v"(code_rows));
@@ -417,6 +427,7 @@ LRM_HD void lrm_tol_plane_tab(const LrmTolTabView& G, uint32_t code, float x, fl
     const float s = __builtin_fmaf(-r, rs, 1.0f); // 1 - r / |p - c|
     du = vx * s;
     dz = vy * s;
+    if (kInfo) *row = wina ? 0u : 0x8000u; // which of the cell's two rows won
     uint32_t lu = 0;
     // An unanswered cell names validity row 31, which lrm_toltab.cpp fills with nan: vacc is nan and fails this test.
     lu |= !(fabsf(vacc) > band) ? LRM_TD_REGION : 0u;
@@ -437,7 +448,13 @@ inline thread_local unsigned long long lrm_tab_host_seconds = 0; // host statist
 // that a candidate is carried as (code, du, w, dz) -- the rotation back to the coxa frame is formed once, for the
 // candidate that wins -- and its plane abscissa is selected from (+-r, uM, um) instead of rotated.
 // p: in = the point, out = the distance vector.  Returns the reach / validity flag.  doubt != 0: do not use the outputs.
-LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p, uint32_t& doubt) {
+// kInfo (LRM_MODE_TOL_REL): *info = what the evaluation DECIDED, for the strict replay of the winner's value chain by the fix-up
+// (lrm_xtab_replay, lrm_point_xtab.h):  bits 0-14 the cell code of the winning candidate's plane point | 15 its second row won |
+// 16-17 the winning candidate's kind (0 own meridian plane, 1 the opposite one, 2 / 3 clamped to the max / min yaw limit) | 18 it is
+// the flipped candidate | 19 its vector is the offset from a yaw-limit plane (the alternative of one_leg.cu:258-274 was taken, or a
+// clamped candidate collapsed onto it) | 20 the flag.
+template <bool kInfo = false>
+LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p, uint32_t& doubt, uint32_t* info = nullptr) {
     const float* a = L.aff;
     const float x = __builtin_fmaf(a[0], p.x, __builtin_fmaf(a[1], p.y, __builtin_fmaf(a[2], p.z, a[3])));
     const float y = __builtin_fmaf(a[4], p.x, __builtin_fmaf(a[5], p.y, __builtin_fmaf(a[6], p.z, a[7])));
@@ -494,7 +511,10 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     // ---- first candidate ----
     float du0, dz0;
     bool valid0;
-    lrm_tol_plane_tab(G, cell0, x0, z, band, tau, du0, dz0, valid0, lu);
+    uint32_t row0 = 0; // kInfo: cell code | winner bit of the winning candidate
+    bool offW = false;
+    lrm_tol_plane_tab<kInfo>(G, cell0, x0, z, band, tau, du0, dz0, valid0, lu, &row0);
+    if (kInfo) row0 |= cell0;
     // A candidate clamped to a yaw limit whose plane point is valid collapses to the offset from that plane, unless
     // sqrt(du^2 + w^2 + dz^2) rounds to |w| (see lrm_dist_tol_t): q / w^2 above 2^-20 collapses, below 2^-25 stays, between: doubt
     {
@@ -503,6 +523,7 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
         const bool collapse = lv && big;
         du0 = collapse ? 0.f : du0;
         dz0 = collapse ? 0.f : dz0;
+        if (kInfo) offW = collapse;
         lu |= (lv && !big) ? LRM_TD_LIMIT : 0u; // (below 2^-25 the reference keeps the vector: one plane point in 1e6, left to the bit-exact code too)
     }
     const float n0 = __builtin_fmaf(du0, du0, __builtin_fmaf(w0, w0, dz0 * dz0));
@@ -522,12 +543,15 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
         const uint32_t codeL = useM ? 2u : 3u;
         const float wL = useM ? wM : wm;
         codeW = alt ? codeL : code0;
+        if (kInfo) offW = offW || alt;
         duW = alt ? 0.f : du0;
         dzW = alt ? 0.f : dz0;
         wW = alt ? wL : w0;
     }
     // ---- the second one only when it can still win: not below its lower bound by more than the tie band ----
     const bool need = two && !flag && !(n0 < b1 - tau * __builtin_fmaf(2.0f, LRM_FAST_SQRT(n0), tau));
+    bool infoB = false;
+    uint32_t codeB = 0;
 #if defined(LRM_TAB_EXP_NO_SECOND) // timing experiment (wrong results): the second candidate is never evaluated
     if (false) {
 #else
@@ -543,7 +567,8 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
         float du1, dz1;
         bool valid1;
         uint32_t bd = 0;
-        lrm_tol_plane_tab(G, cell1, x1, z, band, tau, du1, dz1, valid1, bd);
+        uint32_t row1 = 0;
+        lrm_tol_plane_tab<kInfo>(G, cell1, x1, z, band, tau, du1, dz1, valid1, bd, &row1);
         const float q = __builtin_fmaf(du1, du1, dz1 * dz1), w2 = w1 * w1;
         const bool lv = lim1 && valid1, big = q > w2 * 9.6e-7f;
         const bool collapse = lv && big;
@@ -558,6 +583,12 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
         lu |= need ? bd : 0u;
         const bool useB = need && !(n0 < n1);
         codeW = useB ? code1 : codeW;
+        if (kInfo) { // the second candidate won: its row, its kind, the other flip; its vector is an offset when it collapsed
+            row0 = useB ? (row1 | cell1) : row0;
+            offW = useB ? collapse : offW;
+            infoB = useB;
+            codeB = code1;
+        }
         duW = useB ? du1 : duW;
         wW = useB ? w1 : wW;
         dzW = useB ? dz1 : dzW;
@@ -573,6 +604,11 @@ LRM_HD bool lrm_tab_point(const LrmTolLeg& L, const LrmTolTabView& G, LrmVec3& p
     p.y = __builtin_fmaf(b[3], vx, __builtin_fmaf(b[4], vy, b[5] * vz));
     p.z = __builtin_fmaf(b[6], vx, __builtin_fmaf(b[7], vy, b[8] * vz));
     doubt |= lu;
+    if (kInfo) {
+        const uint32_t codeC = infoB ? codeB : code0;   // the candidate's own kind (codeW names the limit plane when the alternative won)
+        const bool flipC = infoB ? firstD : !firstD;
+        *info = row0 | (codeC << 16) | (flipC ? 0x40000u : 0u) | (offW ? 0x80000u : 0u) | (flag ? 0x100000u : 0u);
+    }
     return flag;
 }
 

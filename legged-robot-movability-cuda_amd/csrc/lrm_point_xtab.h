@@ -28,8 +28,8 @@
 //     yaw by rounding.  A valid direct candidate wins by its flag (the mega candidate is always "saturated"); an INVALID
 //     one is compared with its twin by strict norms -- the reference's pick is rounding noise, so the twin is evaluated too
 //     (same cell, same decisions, its own sincosf / clamp / norm), unless sat_F == yaw bit for bit;
-//   * otherwise the two are different configurations: the table's lower bounds order them and the second one is evaluated
-//     only when it can still win (0.3 % of a random cloud), then compared by strict norms.
+//   * otherwise the two are different configurations: the table's lower bounds order them; a point whose second candidate
+//     can still win (0.3 % of a random cloud) is left to the filtered code (doubt).
 // Everything else the filtered code decides with strict arithmetic (`limit = angle > coxa_mid`, `sat != angle`) is decided
 // here with the same strict comparisons on the same exact angles.
 //
@@ -112,15 +112,15 @@ LRM_HD void lrm_xtab_plane(const LrmTolTabView& G, uint32_t code, float x, float
 //   (s, c)  sincosf(-sat) of the candidate's saturated yaw;  th = -(limit - sat)
 //   cell    the table code of its plane point;  mega: the candidate is mega-saturated (no yaw-limit alternative)
 //   wl      the point's offset from the yaw-limit plane `limit` (decision arithmetic): |wl| is d_limit up to rounding
-// Returns the candidate's vector in the coxa frame; valid = eval_plane_circles' result (the point passes its circles).
+// Returns the candidate's vector in the coxa frame; valid = eval_plane_circles' result (the point passes its circles);
+// (tx, ty, tr) = the clamp target that won (for the twin of an invalid candidate, lrm_xtab_twin).
 LRM_HD LrmVec3 lrm_xtab_chain(const LrmXtabLeg& X, const LrmTolTabView& G, LrmVec3 p, float s, float c, float th, uint32_t cell, bool mega,
-                              float wl, float band, float tau, bool& valid, uint32_t& doubt) {
+                              float wl, float band, float tau, bool& valid, float& tx, float& ty, float& tr, uint32_t& doubt) {
     float buffer = p.x * s; // cancel_coxa_rotation
     p.x = p.x * c - p.y * s;
     p.y = buffer + p.y * c;
     const LrmVec3 save = p;
     const float x = p.x - X.coxa_length; // eval_plane_circles, one_leg.cu:172
-    float tx, ty, tr;
     lrm_xtab_plane(G, cell, x, p.z, band, tau, tx, ty, tr, valid, doubt);
     {   // force_clamp_on_circle onto the winner (one_leg.cu:42-63), then (x, z) -= clamp point (:143-144)
         float cx = x, cy = p.z, d;
@@ -152,7 +152,29 @@ LRM_HD LrmVec3 lrm_xtab_chain(const LrmXtabLeg& X, const LrmTolTabView& G, LrmVe
     return p;
 }
 
-inline thread_local unsigned long long lrm_xtab_host_seconds = 0; // host statistic: points whose second chain ran
+// The twin of an INVALID direct candidate in front of the coxa: the flipped candidate is mega-saturated onto the same meridian
+// plane with sat = (yaw -+ pi) +- pi, the yaw up to rounding.  Same cell, same decisions (the plane point moves by less than an
+// ulp of its coordinates, far inside every band the first candidate had to clear), no yaw-limit alternative (mega): its own
+// sincosf, rotation, strict clamp onto the SAME target, rotation back.
+LRM_HD LrmVec3 lrm_xtab_twin(const LrmXtabLeg& X, LrmVec3 p, float sat, float tx, float ty, float tr) {
+    float s, c;
+    lrm_sincosf(-sat, &s, &c);
+    float buffer = p.x * s;
+    p.x = p.x * c - p.y * s;
+    p.y = buffer + p.y * c;
+    const float x = p.x - X.coxa_length;
+    float cx = x, cy = p.z, d;
+    bool v;
+    lrm_clamp_on(tx, ty, tr, true, cx, cy, d, v);
+    p.x = x - cx;
+    p.z = p.z - cy;
+    buffer = p.y * s;
+    p.y = -p.x * s + p.y * c;
+    p.x = p.x * c + buffer;
+    return p;
+}
+
+inline thread_local unsigned long long lrm_xtab_host_seconds = 0; // host statistic: points whose twin chain ran
 
 // distance_global + reachability_global (one_leg_global.cu:74-130) of one body-frame point.
 // p: in = the point, out = the distance vector.  Returns the flag (distance's validity = the reach mask wherever no decision
@@ -204,56 +226,44 @@ LRM_HD bool lrm_xtab_point(const LrmXtabLeg& X, const LrmTolTabView& G, LrmVec3&
     const bool firstD = inF ? (bD < bF) : (bD <= bF);
     const float b1 = firstD ? bF : bD;
     const bool in0 = firstD ? inD : inF;
-    // the strict yaw-limit bookkeeping of finish_finding_closest for candidate (flip, code):
+    // ---- the first candidate: the strict yaw-limit bookkeeping of finish_finding_closest for candidate (flip, code) ----
     //   direct:  code 0 inside: sat = yaw;        1 mega: sat = yaw -+ pi (= the flipped yaw, the same expression);  2 / 3 clamped
     //   flipped: code 1 inside: sat = yaw -+ pi;  0 mega: sat = (yaw -+ pi) +- pi;                                   2 / 3 clamped
     const float ang_ff = (ang_flip > 0) ? ang_flip - LRM_PI_F : ang_flip + LRM_PI_F;
-    // ---- the candidates: one copy of the value chain, run once or twice ----
-    LrmVec3 v0{0.f, 0.f, 0.f}, v1{0.f, 0.f, 0.f};
-    bool valid0 = false, have1 = false;
-#pragma unroll 1
-    for (int k = 0; k < 2; k++) {
-        const bool flip = k ? firstD : !firstD; // k = 0: the first candidate; k = 1: the other one
-        const uint32_t code = flip ? codeF : codeD;
-        const bool lim = code >= 2u, mn = code == 3u;
-        const bool mega = flip ? (code == 0u) : (code == 1u);
-        const float angle = flip ? ang_flip : ang;
-        const float limit = (angle > X.coxa_mid) ? X.max_coxa : X.min_coxa;
-        const float sat = lim ? (mn ? X.min_coxa : X.max_coxa) : ((code == 1u) ? ang_flip : (flip ? ang_ff : ang));
-        float s = mn ? X.lim_sc[2] : X.lim_sc[0], c = mn ? X.lim_sc[3] : X.lim_sc[1];
-        if (!lim) lrm_sincosf(-sat, &s, &c);
-        const float th = -(limit - sat);
-        const uint32_t cell = lrm_toltab_resolve(G, flip ? cF : cD, flip ? sF : sD, fbase);
-        const float wl = (limit == X.max_coxa) ? wM : wm;
-        bool valid;
-        uint32_t d = 0;
-        const LrmVec3 v = lrm_xtab_chain(X, G, a, s, c, th, cell, mega, wl, band, tau, valid, d);
-        if (k == 0) {
-            v0 = v;
-            valid0 = valid;
-            lu |= d;
-            const bool flag = valid && in0;
-            const float n0 = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, v.z * v.z));
-            // the twin of an invalid direct candidate in front of the coxa (its flipped candidate is mega-saturated onto it)
-            const bool twin = !two && firstD && inD && !valid && (ang_ff != ang);
-            // a different second candidate only when it can still win: not below its lower bound by more than the tie band
-            const bool second = two && !flag && !(n0 < b1 - tau * __builtin_fmaf(2.0f, LRM_FAST_SQRT(n0), tau));
-            have1 = twin || second;
-            if (!LRM_TOL_ANY(have1)) break;
-        } else {
-            v1 = v;
-            lu |= have1 ? d : 0u;
-#if !defined(__HIP_DEVICE_COMPILE__)
-            lrm_xtab_host_seconds++;
-#endif
-        }
+    const bool flip = !firstD;
+    const uint32_t code = flip ? codeF : codeD;
+    const bool lim = code >= 2u, mn = code == 3u;
+    const bool mega = flip ? (code == 0u) : (code == 1u);
+    const float angle = flip ? ang_flip : ang;
+    const float limit = (angle > X.coxa_mid) ? X.max_coxa : X.min_coxa;
+    const float sat = lim ? (mn ? X.min_coxa : X.max_coxa) : ((code == 1u) ? ang_flip : (flip ? ang_ff : ang));
+    float s = mn ? X.lim_sc[2] : X.lim_sc[0], c = mn ? X.lim_sc[3] : X.lim_sc[1];
+    if (!lim) lrm_sincosf(-sat, &s, &c);
+    const float th = -(limit - sat);
+    const uint32_t cell = lrm_toltab_resolve(G, flip ? cF : cD, flip ? sF : sD, fbase);
+    const float wl = (limit == X.max_coxa) ? wM : wm;
+    bool valid;
+    float tx, ty, tr;
+    LrmVec3 rv = lrm_xtab_chain(X, G, a, s, c, th, cell, mega, wl, band, tau, valid, tx, ty, tr, lu);
+    const bool flag = valid && in0;
+    // A DIFFERENT second candidate can still win when the first one is not below its lower bound by more than the tie band
+    // (0.3 % of a random cloud): left to the filtered code.
+    {
+        const float n0 = __builtin_fmaf(rv.x, rv.x, __builtin_fmaf(rv.y, rv.y, rv.z * rv.z));
+        lu |= (two && !flag && !(n0 < b1 - tau * __builtin_fmaf(2.0f, LRM_FAST_SQRT(n0), tau))) ? LRM_TD_PICK : 0u;
     }
-    // distance_circles' pick (one_leg.cu:334).  A second candidate is only ever evaluated next to an unflagged first one, and then
-    // neither is valid-and-unsaturated: res == resflip == false, the strictly shorter DIRECT candidate wins, else the flipped one.
-    LrmVec3 rv = v0;
-    if (have1) {
-        const LrmVec3 da = firstD ? v0 : v1, fb = firstD ? v1 : v0;
-        rv = (lrm_norm3(da) < lrm_norm3(fb)) ? da : fb;
+    // The twin of an invalid direct candidate in front of the coxa: distance_circles' pick (one_leg.cu:334) with
+    // res == resflip == false: the strictly shorter DIRECT candidate, else the flipped one.
+    const bool twin = !two && firstD && inD && !valid && (ang_ff != ang);
+    if (LRM_TOL_ANY(twin)) {
+        const LrmVec3 fb = lrm_xtab_twin(X, a, ang_ff, tx, ty, tr);
+        const bool take = twin && !(lrm_norm3(rv) < lrm_norm3(fb));
+        rv.x = take ? fb.x : rv.x;
+        rv.y = take ? fb.y : rv.y;
+        rv.z = take ? fb.z : rv.z;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        lrm_xtab_host_seconds++;
+#endif
     }
     // place_over_coxa<Reverse>, z_unrotateInPlace, qtRotate
     buffer = rv.x * X.sin_pitch_rev;
@@ -270,5 +280,74 @@ LRM_HD bool lrm_xtab_point(const LrmXtabLeg& X, const LrmTolTabView& G, LrmVec3&
         lu |= !(lim_margin > 2.0e-6f) ? LRM_TD_YAW : 0u;
     }
     doubt |= lu;
-    return valid0 && in0;
+    return flag;
+}
+
+// The strict value chain of ONE point whose decisions are known (LRM_MODE_TOL_REL: the tolerance kernel took them, all outside
+// their bands, and wrote them into the queue record: see lrm_tab_point<true>): no table, no bands, no doubt -- the reference's
+// operations on the winner alone.  p: in = the point, out = the distance vector of distance_global.
+LRM_HD void lrm_xtab_replay(const LrmXtabLeg& X, const LrmTabRow* rows, LrmVec3& p, uint32_t info) {
+    LrmVec3 a = lrm_qrot(X.inv_rot, p);
+    float buffer = a.x * X.sin_body;
+    a.x = a.x * X.cos_body - a.y * X.sin_body;
+    a.y = buffer + a.y * X.cos_body;
+    a.x -= X.body;
+    buffer = a.x * X.sin_pitch;
+    a.x = a.x * X.cos_pitch - a.z * X.sin_pitch;
+    a.z = buffer + a.z * X.cos_pitch;
+    const float ang = lrm_atan2f(a.y, a.x);
+    const float ang_flip = (ang > 0) ? ang - LRM_PI_F : ang + LRM_PI_F;
+    const float ang_ff = (ang_flip > 0) ? ang_flip - LRM_PI_F : ang_flip + LRM_PI_F;
+    const LrmTabRow t = rows[(info & 0x8000u) ? ((info >> 5) & 31u) : (info & 31u)];
+    const uint32_t code = (info >> 16) & 3u;
+    const bool flip = (info & 0x40000u) != 0u, off = (info & 0x80000u) != 0u, flag = (info & 0x100000u) != 0u;
+    // an invalid DIRECT candidate inside the yaw range whose flipped candidate is mega-saturated onto it has a twin (lrm_xtab_point);
+    // the strict comparisons of finish_finding_closest (one_leg.cu:219-220) on the flipped yaw
+    const bool twinp = !flip && code == 0u && ((ang_flip > X.mega_hi) || (ang_flip < X.mega_lo));
+    const bool lim = code >= 2u, mn = code == 3u;
+    const float angle = flip ? ang_flip : ang;
+    const float limit = (angle > X.coxa_mid) ? X.max_coxa : X.min_coxa;
+    const float sat = lim ? (mn ? X.min_coxa : X.max_coxa) : ((code == 1u) ? ang_flip : (flip ? ang_ff : ang));
+    float s = mn ? X.lim_sc[2] : X.lim_sc[0], c = mn ? X.lim_sc[3] : X.lim_sc[1];
+    if (!lim) lrm_sincosf(-sat, &s, &c);
+    LrmVec3 q = a;
+    buffer = q.x * s; // cancel_coxa_rotation
+    q.x = q.x * c - q.y * s;
+    q.y = buffer + q.y * c;
+    if (off) { // the offset from the yaw-limit plane (one_leg.cu:258-274 decided `d_clamped > d_limit`)
+        const float th = -(limit - sat);
+        float s2 = th, c2 = 1.0f;
+        if (th != 0.f) lrm_sincosf(th, &s2, &c2);
+        const float sy = q.x * s2 + q.y * c2;
+        LrmVec3 l = {0.f, sy, 0.f};
+        const float b2 = l.y * s2;
+        l.y = -l.x * s2 + l.y * c2;
+        l.x = l.x * c2 + b2;
+        q = l;
+    } else { // force_clamp_on_circle onto the winner (one_leg.cu:42-63), (x, z) -= clamp point (:143-144)
+        const float x = q.x - X.coxa_length;
+        float cx = x, cy = q.z, d;
+        bool v;
+        lrm_clamp_on(t.x, t.y, t.r, true, cx, cy, d, v);
+        q.x = x - cx;
+        q.z = q.z - cy;
+    }
+    buffer = q.y * s; // restore_coxa_rotation
+    q.y = -q.x * s + q.y * c;
+    q.x = q.x * c + buffer;
+    const bool twin = twinp && !flag && (ang_ff != ang);
+    if (LRM_TOL_ANY(twin)) {
+        const LrmVec3 fb = lrm_xtab_twin(X, a, ang_ff, t.x, t.y, t.r);
+        const bool take = twin && !(lrm_norm3(q) < lrm_norm3(fb));
+        q.x = take ? fb.x : q.x;
+        q.y = take ? fb.y : q.y;
+        q.z = take ? fb.z : q.z;
+    }
+    buffer = q.x * X.sin_pitch_rev;
+    q.x = q.x * X.cos_pitch_rev - q.z * X.sin_pitch_rev;
+    q.z = buffer + q.z * X.cos_pitch_rev;
+    buffer = q.x * -X.sin_body;
+    q.x = q.x * X.cos_body - q.y * -X.sin_body;
+    q.y = buffer + q.y * X.cos_body;
+    p = lrm_qrot(X.fwd_rot, q);
 }

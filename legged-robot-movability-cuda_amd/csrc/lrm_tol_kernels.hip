@@ -56,6 +56,9 @@
 #ifndef LRM_TOL_GRID_MULT
 #define LRM_TOL_GRID_MULT 8
 #endif
+#ifndef LRM_TAB_FIX_SEGS
+#define LRM_TAB_FIX_SEGS 8 // segments per fix-up workgroup: ~60 queued points at the usual 0.5 % of doubt, 1000 workgroups (4 segments, 2000 workgroups: 3 us slower)
+#endif
 
 #if defined(LRM_FIX_TRACE)
 // timing experiment (tools/fix_trace.py): s_memrealtime stamps (100 MHz) of the phases of the fix-up waves and the
@@ -330,20 +333,26 @@ struct TabLds {
     LrmTabVRow vrows[32];
 };
 constexpr int kTabSegCap = LRM_TOL_TAB_SEG_CAP; // doubt slots per workgroup of dist_tab_kernel
-constexpr int kWaveSegCap = LRM_TOL_TAB_SEG_CAP / (LRM_TOL_BLOCK / 64); // ... per wave in LRM_MODE_TOL_REL (the same workspace, cut four ways)
-static_assert(kWaveSegCap * (LRM_TOL_BLOCK / 64) == LRM_TOL_TAB_SEG_CAP, "wave segments tile a workgroup's segment");
+#ifndef LRM_SHORT_CAP
+#define LRM_SHORT_CAP 24 // LDS slots per wave for the short vectors of LRM_MODE_TOL_REL (~8 expected over a wave's life; a record without room joins the doubt queue)
+#endif
+constexpr int kShortCap = LRM_SHORT_CAP;
 constexpr int kTabBoundVecs = LRM_TT_NB * LRM_TT_NB * 4 / 16; // 16-byte pieces of the inner grid's bounds
 static_assert(kTabBoundVecs % kBlock == 0, "every thread stages the same number of pieces");
 // kShort: LRM_MODE_TOL_REL (a template argument: as a run-time flag the compiler computes the norm for every point of every mode)
 template <int kOp, bool kAoS = false, bool kShort = false>
-__global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
+__global__ __launch_bounds__(kBlock, kShort ? LRM_TAB_MIN_WAVES - 1 : LRM_TAB_MIN_WAVES) void dist_tab_kernel( // (kShort carries the info word and the replay tail: spills at 7 waves)
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
-    const LrmTolLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
+    const LrmTolLeg L_kernarg, const LrmXtabLeg X_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ tab, QueueRec* __restrict__ queue,
     uint32_t* __restrict__ counts, uint32_t selftest) {
     __shared__ TabLds s_tab;
     __shared__ uint32_t s_bound[LRM_TT_NB * LRM_TT_NB];
     __shared__ uint32_t s_qn;
+    // LRM_MODE_TOL_REL: the short vectors of this workgroup (4-5 % of a random cloud: ~32 over its life) wait in LDS, a segment per
+    // wave (the count in a scalar register: no atomic), five words per record; the workgroup's first wave replays them at the end
+    __shared__ uint32_t s_short[kShort ? 5 * (kBlock / 64) * kShortCap : 1];
+    __shared__ uint32_t s_wcnt[kBlock / 64];
     const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
     LrmVec3 p_next{0.f, 0.f, 0.f}; // the first point in front of the table staging
@@ -377,12 +386,7 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
     const uint32_t n32 = (uint32_t)n; // the C ABI sends clouds of 0xc0000000 points and more to the bit-exact kernels: indices fit 32 bits
     QueueRec* seg = queue + (size_t)blockIdx.x * kTabSegCap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // LRM_MODE_TOL_REL queues ~5 % of a random cloud: nearly every wave pushes in every round.  Its segments belong to WAVES
-    // (kWaveSegCap slots each, the count in a scalar register: no LDS atomic, no wait on its return in every wave's chain, no
-    // barrier at the end); a record's bit 31 says that a DECISION was in doubt (filtered code), clear = the vector is merely short
-    // (the table-guided bit-exact chain of lrm_point_xtab.h takes it).
-    const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane(wave); // the compiler cannot know that threadIdx.x >> 6 is uniform: without this the segment's address lives in two VGPRs
-    QueueRec* wseg = queue + ((size_t)blockIdx.x * (kBlock / 64) + (size_t)wave_s) * kWaveSegCap;
+    const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane(wave); // (the compiler cannot know that threadIdx.x >> 6 is uniform)
     uint32_t wq = 0;
     const uint32_t toff0 = threadIdx.x * 4u;
     uint32_t round = 0;
@@ -400,12 +404,14 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
         }
         uint32_t doubt = 0;
         const LrmVec3 p_in = p; // kept for the queue record (three registers; re-loading it cost a pushing wave an L2 round trip)
-        const bool m = lrm_tab_point(L, G, p, doubt) && live;
+        uint32_t info = 0; // kShort: what the evaluation decided (the fix-up replays the winner's value chain from it)
+        const bool m = lrm_tab_point<kShort>(L, G, p, doubt, &info) && live;
         doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u; // selftest: every point goes to the fix-up
-        if (kShort) { // LRM_MODE_TOL_REL: a vector shorter than the threshold comes from the bit-exact code; bit 31 = a decision was in doubt
+        bool is_short = false;
+        if (kShort) { // LRM_MODE_TOL_REL: a vector shorter than the threshold (and not in doubt) gets its value chain replayed strictly
             const float nn = __builtin_fmaf(p.x, p.x, __builtin_fmaf(p.y, p.y, p.z * p.z));
             const float short_mm = lrm_tol_rel_threshold(L, p_in); // (from the point kept for the queue record: nothing more stays live across the evaluation)
-            doubt = (doubt ? 0x80000000u : 0u) | ((live && !(nn >= short_mm * short_mm)) ? 1u : 0u);
+            is_short = live && doubt == 0u && !(nn >= short_mm * short_mm);
         }
         if (live) {
             if (kAoS) {
@@ -423,16 +429,29 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
             const uint64_t w = __ballot(m);
             if (lane == 0) lrm_at(bits + (rbase >> 6), lrm_opaque((uint32_t)wave * 8u)) = w;
         }
-        const uint64_t dm = __ballot(doubt != 0);
-        if (kShort) {
-            if (dm) {
-                if (doubt) {
-                    const uint32_t qs = wq + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-                    if (qs < (uint32_t)kWaveSegCap) wseg[qs] = QueueRec{i | (doubt & 0x80000000u), p_in.x, p_in.y, p_in.z}; // beyond: the count tells the fix-up to redo the wave's points
+        if (kShort) { // the wave's LDS segment; a record that finds no room goes to the doubt queue instead (the filtered code takes it)
+            const uint64_t sm = __ballot(is_short);
+#if defined(LRM_EXP_NOPUSH) // timing experiment (wrong results): the short vectors are never recorded
+            if (false) {
+#else
+            if (sm) {
+#endif
+                const uint32_t qs = wq + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+                if (is_short) {
+                    if (qs < (uint32_t)kShortCap) {
+                        uint32_t* r = s_short + 5u * (wave_s * (uint32_t)kShortCap + qs);
+                        r[0] = i;
+                        r[1] = lrm_f2u(p_in.x);
+                        r[2] = lrm_f2u(p_in.y);
+                        r[3] = lrm_f2u(p_in.z);
+                        r[4] = info;
+                    } else doubt = 1u;
                 }
-                wq += (uint32_t)__popcll(dm);
+                wq = min(wq + (uint32_t)__popcll(sm), (uint32_t)kShortCap);
             }
-        } else if (dm) {
+        }
+        const uint64_t dm = __ballot(doubt != 0); // queue A: per-workgroup segment, slots from an LDS counter
+        if (dm) {
             uint32_t qb = 0;
             if (lane == 0) qb = atomicAdd(&s_qn, (uint32_t)__popcll(dm));
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
@@ -442,11 +461,36 @@ __global__ __launch_bounds__(kBlock, LRM_TAB_MIN_WAVES) void dist_tab_kernel(
             }
         }
     }
+    if (kShort && lane == 0) s_wcnt[wave_s] = wq;
+    __syncthreads(); // (also orders this workgroup's stores of the tolerance vectors before the replayed ones below)
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
     if (kShort) {
-        if (lane == 0) counts[blockIdx.x * (kBlock / 64) + wave_s] = wq;
-    } else {
-        __syncthreads();
-        if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
+        // ---- the tail: the workgroup's short vectors, compacted over its waves' segments, one lane per record.  The tolerance
+        // evaluation took every DECISION for them (none in doubt); lrm_xtab_replay recomputes the winner's VALUE chain with the
+        // reference's own operations (no table look-ups, no bands): these vectors are bit-identical to the reference's. ----
+        const LrmXtabLeg& X = lrm_kernarg<LrmXtabLeg>(kTolLegArg + (unsigned)sizeof(LrmTolLeg));
+        static_assert(kBlock / 64 == 4, "four wave segments");
+        const uint32_t c0 = s_wcnt[0], c1 = c0 + s_wcnt[1], c2 = c1 + s_wcnt[2], total = c2 + s_wcnt[3];
+        for (uint32_t k0 = wave_s * 64u; k0 < total; k0 += (uint32_t)kBlock) { // wave-uniform: usually only the first wave has work
+            const uint32_t k = k0 + (uint32_t)lane;
+            if (k < total) {
+                const uint32_t w = (k >= c0 ? 1u : 0u) + (k >= c1 ? 1u : 0u) + (k >= c2 ? 1u : 0u);
+                const uint32_t first = w == 0u ? 0u : (w == 1u ? c0 : (w == 2u ? c1 : c2));
+                const uint32_t* r = s_short + 5u * (w * (uint32_t)kShortCap + (k - first));
+                const size_t i = r[0];
+                LrmVec3 q{lrm_u2f(r[1]), lrm_u2f(r[2]), lrm_u2f(r[3])};
+                lrm_xtab_replay(lrm_fresh(X), s_tab.rows, q, r[4]);
+                if (kAoS) {
+                    dx[3 * i] = q.x;
+                    dx[3 * i + 1] = q.y;
+                    dx[3 * i + 2] = q.z;
+                } else {
+                    dx[i] = q.x;
+                    dy[i] = q.y;
+                    dz[i] = q.z;
+                }
+            }
+        }
     }
 #if defined(LRM_FIX_TRACE)
     if (threadIdx.x == 0 && blockIdx.x < 32768) g_main_trace[blockIdx.x * 2 + 1] = wall_clock64();
@@ -633,10 +677,12 @@ struct FixLds {
 
 // One workgroup: the segments [blockIdx.x * kSegPerWave, +kSegPerWave) of the `nseg` segments (= workgroups) of a main-kernel
 // launch with grid stride `main_stride` points; seg_cap slots per segment.
-template <int kOp, bool kAoS = false, int kSegPerWave = LRM_TOL_SEG_PER_WAVE, int kThreads = kFixBlock>
-__global__ __launch_bounds__(kThreads) void tol_fixup_kernel(
-    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
-    const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
+// (a device function: tol_fixup_kernel is it, and the fix-up launch of LRM_MODE_TOL_REL runs it in its second kind of workgroups;
+// bid = the workgroup's number among those that run it, L = the leg in the caller's kernarg segment)
+template <int kOp, bool kAoS, int kSegPerWave, int kThreads>
+__device__ __forceinline__ void tol_fixup_body(
+    const uint32_t bid, const LrmCompiledLeg& L, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
+    uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const QueueRec* __restrict__ queue,
     const uint32_t* __restrict__ counts, uint32_t nseg, uint32_t seg_cap, size_t main_stride, uint32_t selftest) {
     __shared__ FixLds s_tab;
@@ -644,8 +690,7 @@ __global__ __launch_bounds__(kThreads) void tol_fixup_kernel(
     constexpr uint32_t kQueueAhead = kThreads / kSegPerWave;
     static_assert(kSegPerWave * kQueueAhead <= kThreads, "one slot per thread");
     __shared__ QueueRec s_q[kSegPerWave][kQueueAhead];
-    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kFixLegArg);
-    const uint32_t seg0 = blockIdx.x * kSegPerWave;
+    const uint32_t seg0 = bid * kSegPerWave;
     const int lane = threadIdx.x;
     LRM_TRACE_FIX(0);
     // This kernel is a chain of latencies (launch, counts, tables, gather, ~2000 dependent instructions of the exact
@@ -741,154 +786,14 @@ __global__ __launch_bounds__(kThreads) void tol_fixup_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// The fix-up of LRM_MODE_TOL_REL (round 4).  Its queue holds 5 % of a random cloud -- the vectors shorter than
-// lrm_tol_rel_threshold next to the usual 0.5 % of doubtful points -- in per-wave segments (dist_tab_kernel<.., kShort>).
-// Round 3 pushed all of them through tol_fixup_kernel, a latency chain shaped for 4e4 points: +37 us per 1e7 points.  Here
-//   phase B  one lane per record, every thread of the workgroup busy: a record without the "hard" bit runs the table-guided
-//            bit-exact chain (lrm_xtab_point: one yaw candidate, one strict clamp) and stores its result; a hard record, or
-//            one the chain itself doubts, is appended to the workgroup's slow list (LDS);
-//   phase A  the slow list (the 0.5 %) through the filtered code, two lanes per point, exactly as tol_fixup_kernel.
-// One workgroup: kSegs wave segments.  An overflowed segment has all the points of its wave redone by phase A's code.
-// ------------------------------------------------------------------------------------------------------------
-struct KernargRelFix {
-    const float *x, *y, *z;
-    size_t n;
-    LrmCompiledLeg L;
-    LrmXtabLeg X;
-};
-constexpr unsigned kRelFixLegArg = (unsigned)offsetof(KernargRelFix, L), kRelFixXArg = (unsigned)offsetof(KernargRelFix, X);
-#ifndef LRM_REL_FIX_SEGS
-#define LRM_REL_FIX_SEGS 32
-#endif
-template <int kOp, bool kAoS = false, int kSegs = LRM_REL_FIX_SEGS, int kThreads = 256>
-__global__ __launch_bounds__(kThreads) void rel_fixup_kernel(
+template <int kOp, bool kAoS = false, int kSegPerWave = LRM_TOL_SEG_PER_WAVE, int kThreads = kFixBlock>
+__global__ __launch_bounds__(kThreads) void tol_fixup_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
-    const LrmCompiledLeg L_kernarg, const LrmXtabLeg X_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
-    float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ tab, const QueueRec* __restrict__ queue,
-    const uint32_t* __restrict__ counts, uint32_t nseg, size_t main_stride, uint32_t selftest) {
-    __shared__ FixLds s_tab;
-    __shared__ TabLds s_rows;
-    __shared__ uint32_t s_pre[kSegs + 1], s_cnt[kSegs];
-    __shared__ uint32_t s_slow[kSegs * kWaveSegCap]; // record ordinals of the slow list
-    __shared__ uint32_t s_nslow;
-    static_assert(kSegs <= 64, "one wave scans the counts");
-    const LrmCompiledLeg& L = lrm_kernarg<LrmCompiledLeg>(kRelFixLegArg);
-    const LrmXtabLeg& X = lrm_kernarg<LrmXtabLeg>(kRelFixXArg);
-    const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
-    const uint32_t seg0 = blockIdx.x * kSegs;
-    const int tid = threadIdx.x;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(&L.lists[0][0]);
-        const uint4* dsrc = reinterpret_cast<const uint4*>(&L.dist_tab[0][0]);
-        const uint4* csrc = reinterpret_cast<const uint4*>(&L.corner_tab[0]);
-        const uint4* rsrc = reinterpret_cast<const uint4*>(&hd->rows[0]);
-        for (int i = tid; i < (int)(sizeof(s_tab.lists) / 16); i += kThreads) reinterpret_cast<uint4*>(s_tab.lists)[i] = src[i];
-        for (int i = tid; i < (int)(sizeof(s_tab.dist) / 16); i += kThreads) reinterpret_cast<uint4*>(s_tab.dist)[i] = dsrc[i];
-        for (int i = tid; i < (int)(sizeof(s_tab.corners) / 16); i += kThreads) reinterpret_cast<uint4*>(s_tab.corners)[i] = csrc[i];
-        for (int i = tid; i < (int)(sizeof(TabLds) / 16); i += kThreads) reinterpret_cast<uint4*>(&s_rows)[i] = rsrc[i];
-    }
-    if (tid < 64) { // wave 0: the counts and their exclusive prefix (an overflowed segment contributes nothing: it is redone as a whole)
-        const uint32_t c = (tid < kSegs && seg0 + tid < nseg) ? counts[seg0 + tid] : 0u;
-        const uint32_t v = c <= (uint32_t)kWaveSegCap ? c : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
-            if (tid >= off) incl += t;
-        }
-        if (tid < kSegs) { s_cnt[tid] = c; s_pre[tid] = incl - v; }
-        if (tid == kSegs - 1) s_pre[kSegs] = incl;
-        if (tid == 0) s_nslow = 0;
-    }
-    __syncthreads();
-    const uint32_t total = s_pre[kSegs];
-    bool any_over = false;
-    for (int j = 0; j < kSegs; j++) any_over = any_over || s_cnt[j] > (uint32_t)kWaveSegCap;
-    if (total == 0 && !any_over) return; // workgroup-uniform
-    const uint32_t* bound_glob = reinterpret_cast<const uint32_t*>(tab + sizeof(LrmTolTabHeader) + 2 * (size_t)hd->bound_off[0]);
-    const LrmTolTabView G = lrm_toltab_view(tab, s_rows.rows, s_rows.vrows, bound_glob, X.r_outer);
-    auto record = [&](uint32_t k) -> QueueRec { // record number k of this workgroup's segments
-        int j = 0;
-#pragma unroll
-        for (int step = kSegs / 2; step >= 1; step >>= 1) j += (s_pre[j + step] <= k) ? step : 0; // kSegs is a power of two
-        return queue[(size_t)(seg0 + j) * kWaveSegCap + (k - s_pre[j])];
-    };
-    static_assert((kSegs & (kSegs - 1)) == 0, "binary search over the prefix");
-    // ---- phase B ----
-    for (uint32_t k0 = 0; k0 < total; k0 += kThreads) { // workgroup-uniform trip count
-        const uint32_t k = k0 + (uint32_t)tid;
-        bool slow = false;
-        if (k < total) {
-            const QueueRec rec = record(k);
-            slow = (rec.i >> 31) != 0u;
-            const size_t i = rec.i & 0x7fffffffu;
-            LrmVec3 p{rec.x, rec.y, rec.z};
-            uint32_t doubt = 0;
-            const bool m = lrm_xtab_point(lrm_fresh(X), G, p, doubt);
-            slow = slow || (doubt & 0xffffu) != 0u || (selftest & 2u) != 0u;
-            if (!slow) {
-                if (kAoS) {
-                    dx[3 * i] = p.x;
-                    dx[3 * i + 1] = p.y;
-                    dx[3 * i + 2] = p.z;
-                } else {
-                    dx[i] = p.x;
-                    dy[i] = p.y;
-                    dz[i] = p.z;
-                }
-                // (mask and bit word: the flag of the tolerance kernel stands -- it is the same decision)
-            }
-        }
-        const uint64_t sm = __ballot(slow);
-        if (sm) {
-            uint32_t base = 0;
-            if ((tid & 63) == 0) base = atomicAdd(&s_nslow, (uint32_t)__popcll(sm));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (slow) s_slow[base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u))] = k;
-        }
-    }
-    __syncthreads();
-    // ---- phase A: the filtered code, two lanes per point (see tol_fixup_kernel) ----
-    const LrmDistTables T{s_tab.lists, s_tab.dist, s_tab.corners, (selftest & 2u) ? 1u : 0u};
-    constexpr int kPerPass = kThreads / 2;
-    const int slot = tid >> 1, cand = tid & 1;
-    auto redo = [&](size_t i, LrmVec3 p, bool live) {
-        const bool m = lrm_redo_pair<kOp>(L, T, p, cand);
-        if (live && cand == 0) {
-            if (kAoS) {
-                dx[3 * i] = p.x;
-                dx[3 * i + 1] = p.y;
-                dx[3 * i + 2] = p.z;
-            } else {
-                dx[i] = p.x;
-                dy[i] = p.y;
-                dz[i] = p.z;
-            }
-            if (mask) mask[i] = m;
-            if (bits) patch_bit(bits, i, m);
-        }
-    };
-    const uint32_t nslow = s_nslow;
-    for (uint32_t k0 = 0; k0 < nslow; k0 += kPerPass) { // workgroup-uniform trip count
-        const uint32_t k = k0 + (uint32_t)slot;
-        const bool live = k < nslow;
-        QueueRec rec{0u, 300.f, 0.f, -100.f}; // a lane without a point evaluates a harmless one
-        if (live) rec = record(s_slow[k]);
-        redo((size_t)(rec.i & 0x7fffffffu), LrmVec3{rec.x, rec.y, rec.z}, live);
-    }
-    if (!any_over || main_stride == 0) return;
-    for (int j = 0; j < kSegs; j++) {
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[j]) <= (uint32_t)kWaveSegCap) continue;
-        // every point of wave segment seg0 + j: i = (seg0 + j) * 64 + lane + round * main_stride
-        for (size_t base = (size_t)(seg0 + j) * 64; base < n; base += main_stride) {
-            const size_t i = base + (size_t)slot;
-            const bool live = slot < 64 && i < n;
-            LrmVec3 p{300.f, 0.f, -100.f};
-            if (live) p = kAoS ? LrmVec3{x[3 * i], x[3 * i + 1], x[3 * i + 2]} : LrmVec3{x[i], y[i], z[i]};
-            redo(i, p, live);
-        }
-    }
+    const LrmCompiledLeg L_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
+    float* __restrict__ dy, float* __restrict__ dz, const QueueRec* __restrict__ queue,
+    const uint32_t* __restrict__ counts, uint32_t nseg, uint32_t seg_cap, size_t main_stride, uint32_t selftest) {
+    tol_fixup_body<kOp, kAoS, kSegPerWave, kThreads>(blockIdx.x, lrm_kernarg<LrmCompiledLeg>(kFixLegArg), x, y, z, n, mask, bits, dx, dy, dz, queue, counts,
+                                                     nseg, seg_cap, main_stride, selftest);
 }
 
 } // namespace
@@ -944,9 +849,6 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
 #ifndef LRM_TAB_FIX_BLOCK_REL
 #define LRM_TAB_FIX_BLOCK_REL 256 // of 256 threads: two passes of 128 points
 #endif
-#ifndef LRM_TAB_FIX_SEGS
-#define LRM_TAB_FIX_SEGS 8 // segments per fix-up workgroup: ~60 queued points at the usual 0.5 % of doubt, 1000 workgroups (4 segments, 2000 workgroups: 3 us slower)
-#endif
 static size_t tab_main_blocks(size_t n) {
     const size_t base = (size_t)256 * LRM_TAB_MIN_WAVES * LRM_TAB_GRID_MULT; // workgroups of four waves: every resident slot LRM_TAB_GRID_MULT times over
     const size_t need = (n + kBlock - 1) / kBlock;
@@ -955,7 +857,7 @@ static size_t tab_main_blocks(size_t n) {
     if (blocks == 0) blocks = 1;
     return blocks;
 }
-size_t lrm_tol_tab_queue_words(size_t n) { return tab_main_blocks(n) * (4 * (size_t)kTabSegCap + 4); }
+size_t lrm_tol_tab_queue_words(size_t n) { return tab_main_blocks(n) * (4 * (size_t)kTabSegCap + 4); } // counts (padded to 16 bytes per workgroup) | 16-byte records
 size_t lrm_tol_tab_segments(size_t n) { return tab_main_blocks(n); }
 template <int kOp, bool kAoS>
 static hipError_t launch_tab(const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const LrmXtabLeg& X,
@@ -965,24 +867,17 @@ static hipError_t launch_tab(const float* x, const float* y, const float* z, siz
     uint32_t* counts = workspace;
     QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
     if (flags & LRM_TOLF_SHORT)
-        hipLaunchKernelGGL((dist_tab_kernel<kOp, kAoS, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts,
+        hipLaunchKernelGGL((dist_tab_kernel<kOp, kAoS, true>), dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, X, mask, bits, dx, dy, dz, tab_dev, queue, counts,
                            flags | tol_selftest_env());
     else
-        hipLaunchKernelGGL((dist_tab_kernel<kOp, kAoS, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, mask, bits, dx, dy, dz, tab_dev, queue, counts,
+        hipLaunchKernelGGL((dist_tab_kernel<kOp, kAoS, false>), dim3((unsigned)blocks), dim3(kBlock), 0, st, x, y, z, n, TL, X, mask, bits, dx, dy, dz, tab_dev, queue, counts,
                            flags | tol_selftest_env());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t stride = blocks * kBlock;
-    if (flags & LRM_TOLF_SHORT) { // per-wave segments: throughput pass + the filtered code for the slow list (rel_fixup_kernel)
-        const size_t nseg = blocks * (kBlock / 64);
-        const unsigned fblocks = (unsigned)((nseg + LRM_REL_FIX_SEGS - 1) / LRM_REL_FIX_SEGS);
-        hipLaunchKernelGGL((rel_fixup_kernel<kOp, kAoS>), dim3(fblocks), dim3(256), 0, st, x, y, z, n, L, X, mask, bits, dx, dy, dz, tab_dev, queue, counts,
-                           (uint32_t)nseg, stride, flags | tol_selftest_env());
-    } else {
-        const unsigned fblocks = (unsigned)((blocks + LRM_TAB_FIX_SEGS - 1) / LRM_TAB_FIX_SEGS);
-        hipLaunchKernelGGL((tol_fixup_kernel<kOp, kAoS, LRM_TAB_FIX_SEGS>), dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts,
-                           (uint32_t)blocks, (uint32_t)kTabSegCap, stride, flags | tol_selftest_env());
-    }
+    const unsigned fblocks = (unsigned)((blocks + LRM_TAB_FIX_SEGS - 1) / LRM_TAB_FIX_SEGS);
+    hipLaunchKernelGGL((tol_fixup_kernel<kOp, kAoS, LRM_TAB_FIX_SEGS>), dim3(fblocks), dim3(kFixBlock), 0, st, x, y, z, n, L, mask, bits, dx, dy, dz, queue, counts,
+                       (uint32_t)blocks, (uint32_t)kTabSegCap, stride, flags | tol_selftest_env());
     return hipGetLastError();
 }
 hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,

@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--reps", type=int, default=300)
-    ap.add_argument("--modes", default="tol,fast,strict")
+    ap.add_argument("--modes", default="tol,fast,strict", help="comma-separated: tol, tol_rel, fast, strict")
     ap.add_argument("--leg", default="m2", choices=["m2", "moonbot"])
     ap.add_argument("--azimut", type=float, default=0.0, help="body angle of the leg (rad)")
     ap.add_argument("--cloud", default="cube", choices=["cube", "grid", "reachable", "far"],

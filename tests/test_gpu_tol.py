@@ -154,8 +154,8 @@ def test_tol_full_size_config2_1e7_points(lrm, oracle, torch_cuda):
 @pytest.mark.parametrize("n,legname,q", [(3_000_000, "m2", None), (300_000, "moonbot", (0.9397, 0, 0, 0.342)), (150_000, "m2", (0.9848, 0, 0.1736, 0))])
 def test_tol_rel_mode_meets_the_literal_contract(lrm, oracle, torch_cuda, n, legname, q):
     """LRM_MODE_TOL_REL: reach mask bit-exact and |d - d_ref| <= 1e-5 |d_ref| for EVERY vector -- the text of BASELINE.json without a
-    floor.  Vectors that come out shorter than max(17 mm, 2000 decision bands) are queued and computed by the bit-exact code (bit-identical: relative
-    error 0), every longer one is within 1e-5 relative by the tolerance arithmetic itself.  With the table kernel (3e6, 3e5
+    floor.  Vectors that come out shorter than max(17 mm, 2000 decision bands) get their value chain replayed with the reference's own operations
+    (bit-identical: relative error 0), every longer one is within 1e-5 relative by the tolerance arithmetic itself.  With the table kernel (3e6, 3e5
     points) and the staged one (1.5e5)."""
     pts = random_cloud(n, seed=77)
     leg = lrm.get_M2_leg(0.3) if legname == "m2" else lrm.get_moonbot_leg(-1.1)
@@ -179,14 +179,15 @@ def test_tol_rel_mode_meets_the_literal_contract(lrm, oracle, torch_cuda, n, leg
     short = nref < 16.0
     assert bits_equal(d[short], want_d[short]).all()  # bit for bit, zero vectors (reachable points) included
     print(f"relative mode, {n} points: max literal relative error {float((err[nref > 0] / nref[nref > 0]).max()):.3e}; "
-          f"{short.mean():.4f} of the vectors < 16 mm; {nq / npts:.4f} of the cloud through the fix-up, {nover} segments overflowed")
-    assert npts == n and nover == 0 and short.mean() <= nq / npts < 0.2
+          f"{short.mean():.4f} of the vectors < 16 mm (replayed strictly inside the main kernel); {nq / npts:.4f} of the cloud through the fix-up, "
+          f"{nover} segments overflowed")
+    assert npts == n and nover == 0 and nq / npts < (0.03 if n >= 200_000 else 0.2)  # (below 2e5 points the staged kernel queues the short vectors for the fix-up)
 
 
 def test_tol_rel_full_size_config2_1e7_points_against_the_oracle(lrm, oracle, torch_cuda):
     """The bench headline (LRM_MODE_TOL_REL on BASELINE config 2 at full size) against the ORACLE on all 1e7 points: reach mask
     and ballot words bit-identical, |d - d_ref| <= 1e-5 |d_ref| for EVERY vector (0 for a zero reference vector), every vector
-    the oracle gives shorter than 16 mm bit-identical (it came from the bit-exact chain)."""
+    the oracle gives shorter than 16 mm bit-identical (its value chain was replayed strictly, or the filtered code redid it)."""
     from concurrent.futures import ThreadPoolExecutor
     n = 10_000_000
     pts = random_cloud(n, seed=42)
@@ -222,31 +223,35 @@ def test_tol_rel_full_size_config2_1e7_points_against_the_oracle(lrm, oracle, to
         n_exact += int(same.sum())
     print(f"config 2, relative tolerance mode: max literal relative error {worst:.3e} over 1e7 vectors; {n_short / n:.4f} shorter than 16 mm, "
           f"{n_exact / n:.4f} bit-identical; {nq / npts:.4f} of the cloud through the fix-up, {nover} segments overflowed")
-    assert npts == n and nover == 0 and nq / npts < 0.08
+    assert npts == n and nover == 0 and nq / npts < 0.02 and n_exact >= n_short
 
 
-def test_tol_rel_short_vector_cloud_overflows_its_wave_segments(lrm, oracle, torch_cuda):
-    """A cloud in which most vectors are short (points pushed onto the workspace boundary): the per-wave queue segments of
-    LRM_MODE_TOL_REL overflow and the fix-up redoes those waves' points with the filtered code -- slow, never wrong."""
-    n = 400_000
+def test_tol_rel_short_vector_cloud_overflows_its_wave_segments(lrm, torch_cuda):
+    """A cloud in which most vectors are short (points pushed onto the workspace boundary, 6e6 of them): the per-wave LDS segments of
+    LRM_MODE_TOL_REL (24 slots) fill up, the records without room join the doubt queue, whose segments overflow in turn, and the
+    fix-up redoes those workgroups' points with the filtered code -- slow, never wrong.  Against the bit-exact mode on the device (itself checked against
+    the oracle by tests/test_gpu_parity.py)."""
+    torch = torch_cuda
+    n = 6_000_000
     pts = random_cloud(n, seed=5)
     leg = lrm.get_M2_leg(0.0)
-    d0, _ = oracle.dist(pts, leg)
-    rng = np.random.default_rng(6)
-    pts = (pts - d0 + rng.normal(size=(n, 3)) * 2.0).astype(np.float32)  # within a few mm of the boundary
-    x, y, z = soa(torch_cuda, pts)
+    x, y, z = soa(torch, pts)
+    lrm.set_mode(lrm.MODE_FAST)
+    _, d0 = lrm.device.reach_dist(x, y, z, leg, None)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6)
+    near = (torch.stack([x, y, z]) - d0 + torch.randn((3, n), device="cuda", generator=g) * 2.0).contiguous()  # within a few mm of the boundary
+    m1, d1 = lrm.device.reach_dist(near[0], near[1], near[2], leg, None)
     lrm.set_mode(lrm.MODE_TOL_REL)
     try:
-        m, d = lrm.device.reach_dist(x, y, z, leg, None)
-        torch_cuda.cuda.synchronize()
+        m2, d2 = lrm.device.reach_dist(near[0], near[1], near[2], leg, None)
+        torch.cuda.synchronize()
         npts, nq, nover = lrm.dbg_tol_queue_counts()
     finally:
         lrm.set_mode(lrm.MODE_TOL)
-    want_d, _ = oracle.dist(pts, leg)
-    assert np.array_equal(m.cpu().numpy(), oracle.reach(pts, leg))
-    err = np.linalg.norm(d.cpu().numpy().T.astype(np.float64) - want_d.astype(np.float64), axis=1)
-    nref = np.linalg.norm(want_d.astype(np.float64), axis=1)
-    assert (err <= TOL * nref).all()
+    assert torch.equal(m1, m2)
+    err = (d2.double() - d1.double()).norm(dim=0)
+    assert bool((err <= TOL * d1.double().norm(dim=0)).all())
     assert nover > 0 and nq > 0.5 * npts, (nq, nover)
 
 

@@ -51,7 +51,7 @@ def test_xtab_random_cloud_vs_oracle(lrm, oracle, legname, az):
         want_d, want_v = oracle.dist(pts, leg, q)
         frac, stats = check(lrm, pts, leg, q, oracle.reach(pts, leg, q), want_v, want_d, 0.02)
         # the twin of an invalid direct candidate in front of the coxa + the rare real second candidates
-        assert stats["second_chains"] <= 0.35 * len(pts)
+        assert stats["second_chains"] <= 0.35 * len(pts)  # the twin of an invalid direct candidate in front of the coxa
 
 
 @pytest.mark.parametrize("shift", [900.0, 4000.0])
@@ -84,3 +84,34 @@ def test_xtab_nonfinite_inputs_are_in_doubt(lrm):
     pts = np.array([[np.nan, 0, 0], [np.inf, 1, 2], [1e30, 1e30, -1e30], [0, 0, 0], [181.0, 0.0, 0.0]], np.float32)
     _, _, doubt, _ = lrm.dbg_xtab_host(pts, lrm.get_M2_leg(0.0))
     assert (doubt[:3] != 0).all()
+
+
+@pytest.mark.parametrize("legname,az", [("m2", 0.0), ("moonbot", np.pi / 3), ("m2", -2.0)])
+def test_replay_of_the_tolerance_decisions_is_bit_exact(lrm, oracle, legname, az):
+    """LRM_MODE_TOL_REL's short-vector path: the tolerance evaluation takes the decisions (clamp target, candidate, yaw-limit
+    alternative), the fix-up replays the winner's value chain with the reference's own operations (lrm_xtab_replay) -- no table, no
+    bands.  For EVERY point the tolerance evaluation does not doubt (not only the short vectors) the replay must give the oracle's
+    vector bit for bit."""
+    leg = lrm.get_M2_leg(az) if legname == "m2" else lrm.get_moonbot_leg(az)
+    pts = random_cloud(200_000, seed=9)
+    for q in QUATS:
+        m, d, doubt = lrm.dbg_replay_host(pts, leg, q)
+        want_d, want_v = oracle.dist(pts, leg, q)
+        sure = (doubt & 0xffff) == 0
+        assert np.array_equal(m[sure], oracle.reach(pts, leg, q)[sure])
+        same = bits_equal(d[sure], want_d[sure]).all(axis=1)
+        bad = np.flatnonzero(~same)
+        assert len(bad) == 0, (f"{len(bad)} of {int(sure.sum())} replayed vectors are not bit-identical; first: point {pts[sure][bad[0]]}, "
+                               f"got {d[sure][bad[0]]}, want {want_d[sure][bad[0]]}")
+        assert sure.mean() > 0.98
+
+
+@pytest.mark.parametrize("name", golden_cases("cube") + golden_cases("grid") + golden_cases("boundary") + golden_cases("special"))
+def test_replay_on_the_reference_fixtures(lrm, name):
+    c = load_case(name)
+    if not lrm.dbg_tol_ok(c["leg"], c["quat"]):
+        pytest.skip("leg not eligible")
+    m, d, doubt = lrm.dbg_replay_host(c["points"], c["leg"], c["quat"])
+    sure = (doubt & 0xffff) == 0
+    assert np.array_equal(m[sure], c["mask"][sure])
+    assert bits_equal(d[sure], c["dist"][sure]).all()
