@@ -668,7 +668,7 @@ def main():
         total_evals = float(n_total) * args.steps
         achieved = BYTES_PER_EVAL["reach_dist"] * n / (kernel_ms * 1e-3) / 1e9
         kname = {"tol": "dist_tab_kernel<2, false, false> + tol_fixup_kernel<2, false, 8, 128> (one step = both launches)",
-                 "tol_rel": "dist_tab_kernel<2, false, true> + rel_fixup_kernel<2, false, 32, 256> (one step = both launches)",
+                 "tol_rel": "dist_tab_kernel<2, false, true> (tolerance evaluation + strict replay of its short vectors) + tol_fixup_kernel<2, false, 8, 128> (one step = both launches)",
                  "fast": "dist_xtab_kernel<2, false> + tol_fixup_kernel<2, false, 8, 128> (one step = both launches)",
                  "strict": "dist_soa_kernel<2, false>"}[args.mode]
         prof = committed_profile(n, args.mode)

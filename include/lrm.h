@@ -161,7 +161,8 @@ int lrm_rbdl_equiv_cpu(const float* xyz_aos, size_t n, const LrmLegDimensions* l
  * variant with identical results.
  * LRM_MODE_STRICT / LRM_MODE_FAST: nothing but the launch (no allocation, no host synchronisation).
  * LRM_MODE_TOL (distance / fused calls): the first call for a (leg, orientation) compiles the mode's tables on the
- * host (~0.3 ms; + ~30 ms once for the plane table of clouds of >= 2e5 points), uploads them, and allocates the doubt
+ * host (~0.3 ms) and builds the plane table for clouds of >= 2e5 points on the device (< 1 ms on the call's stream, one small
+ * read-back; LRM_TOLTAB_HOST=1: the host builder, ~30 ms), and allocates the doubt
  * queues of this (device, stream); a later call with a larger n regrows the queues (hipFree + hipMalloc: a device-wide
  * synchronisation).  lrm_tol_prepare does all of that ahead of time, after which the calls only launch -- graph
  * capture and latency-critical loops call it first.  The table cache holds 64 (leg, orientation) pairs, least
@@ -364,6 +365,11 @@ int lrm_dbg_xtab_host(const float* xyz_aos, size_t n, const LrmLegDimensions* le
  * those vectors equal lrm_dist_cpu bit for bit (tests/test_xtab_cpu.py).  A point in doubt keeps the tolerance vector. */
 int lrm_dbg_replay_host(const float* xyz_aos, size_t n, const LrmLegDimensions* leg, const float* quat,
                         uint8_t* mask_out, float* dxyz_out, uint32_t* doubt_out);
+/* The plane table of (leg, quat) as the HOST builder (device = 0: csrc/lrm_toltab.cpp) or the DEVICE builder (device = 1:
+ * csrc/lrm_toltab_dev.hip, on the current device) makes it: its bytes into out[cap] (when they fit; out may be NULL), its size, the
+ * build's milliseconds.  The two must agree byte for byte (tests/test_gpu_toltab.py). */
+int lrm_dbg_toltab_build(const LrmLegDimensions* leg, const float* quat, int device, uint8_t* out, size_t cap, size_t* size_out,
+                         float* ms_out);
 /* The plane table's lower bound of the in-plane distance at n plane points xz[2 n] (abscissa - coxa_length, z), next to the
  * full plane evaluation there: distance sqrt(du^2 + dz^2), validity, doubt bits.  The bound must not exceed the distance
  * of an invalid point and must be 0 at a valid one (tests/test_tol_cpu.py). */

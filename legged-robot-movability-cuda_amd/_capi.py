@@ -86,6 +86,7 @@ def load():
         "lrm_dbg_toltab_bounds": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_xtab_host": [vp, sz, vp, vp, vp, vp, vp, vp],
         "lrm_dbg_replay_host": [vp, sz, vp, vp, vp, vp, vp],
+        "lrm_dbg_toltab_build": [vp, vp, C.c_int, vp, sz, vp, vp],
         "lrm_shard_bounds": [sz, C.c_int, C.c_int, sz, vp, vp],
         "lrm_dbg_pair_counts": [vp],
         "lrm_tol_prepare": [vp, vp, sz, vp],
@@ -463,6 +464,16 @@ def dbg_replay_host(xyz, leg, quat=None):
     mask, d, doubt = np.zeros(n, np.uint8), np.zeros_like(xyz), np.zeros(n, np.uint32)
     check(load().lrm_dbg_replay_host(_ptr(xyz), n, _ptr(_f32(leg, (14,))), _ptr(_quat(quat)), _ptr(mask), _ptr(d), _ptr(doubt)))
     return mask, d, doubt
+
+
+def dbg_toltab_build(leg, quat=None, device=False):
+    """the plane table of (leg, quat) from the host builder or the device builder -> (bytes as uint8 array, build milliseconds)"""
+    size, ms = C.c_size_t(0), C.c_float(0)
+    legp, q = _f32(leg, (14,)), _quat(quat)
+    buf = np.zeros(24 << 20, np.uint8)
+    check(load().lrm_dbg_toltab_build(_ptr(legp), _ptr(q), 1 if device else 0, _ptr(buf), buf.size, C.byref(size), C.byref(ms)))
+    assert size.value <= buf.size
+    return buf[:size.value].copy(), float(ms.value)
 
 
 def dbg_toltab_bounds(xz, leg, quat=None):

@@ -169,26 +169,49 @@ bool xtab_wanted(size_t n) {
     if (e && e[0] == '0') return false;
     return tol_tab_wanted(n);
 }
-// device copy of the table of E on the current device, or null (no table for this leg); rc != LRM_OK on a HIP error
+// The table of E on the current device, or null (no table for this leg); rc != LRM_OK on a HIP error.  Built by the device
+// builder (lrm_toltab_dev.hip, on `stream`: < 1 ms) unless LRM_TOLTAB_HOST=1 asks for the host builder or the device builder
+// declines the leg (the host builder's ~30 ms + an upload); the two give the same bytes (tests/test_gpu_toltab.py).
+bool toltab_host_wanted() {
+    const char* e = std::getenv("LRM_TOLTAB_HOST");
+    return e && e[0] == '1';
+}
 int tol_tab_device(TolEntry& E, void* stream, const uint8_t** out) {
     *out = nullptr;
-    if (E.tab_state == 0) {
-        const auto t0 = std::chrono::steady_clock::now();
-        E.tab_state = lrm_build_tol_tab(E.tl, &E.tab) ? 1 : -1;
-        E.tab_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        g_last_tab_build_ms = E.tab_build_ms;
-    }
     if (E.tab_state < 0) return LRM_OK;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
     uint8_t*& td = E.tab_dev[dev];
     if (!td) {
-        void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, E.tab.size()), "hipMalloc plane table");
-        td = static_cast<uint8_t*>(p);
-        HIP_TRY(hipMemcpy(td, E.tab.data(), E.tab.size(), hipMemcpyHostToDevice), "hipMemcpy plane table");
+        bool host = toltab_host_wanted() || !E.tab.empty();
+        if (!host) {
+            uint8_t* t = nullptr;
+            size_t bytes = 0;
+            float ms = 0.f;
+            const int rc = lrm_build_tol_tab_dev(E.tl, (hipStream_t)stream, &t, &bytes, &ms);
+            if (rc < 0) return hip_fail((hipError_t)(-rc), "plane table (device build)");
+            if (rc == 1) { E.tab_state = -1; return LRM_OK; }
+            if (rc == 0) {
+                td = t;
+                E.tab_state = 1;
+                E.tab_build_ms = ms;
+                g_last_tab_build_ms = ms;
+            } else host = true; // the device builder declines this leg
+        }
+        if (host) {
+            if (E.tab.empty()) {
+                const auto t0 = std::chrono::steady_clock::now();
+                E.tab_state = lrm_build_tol_tab(E.tl, &E.tab) ? 1 : -1;
+                E.tab_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                g_last_tab_build_ms = E.tab_build_ms;
+                if (E.tab_state < 0) { E.tab.clear(); return LRM_OK; }
+            }
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, E.tab.size()), "hipMalloc plane table");
+            td = static_cast<uint8_t*>(p);
+            HIP_TRY(hipMemcpy(td, E.tab.data(), E.tab.size(), hipMemcpyHostToDevice), "hipMemcpy plane table");
+        }
     }
-    (void)stream;
     *out = td;
     return LRM_OK;
 }
@@ -229,7 +252,7 @@ int launch_dist_any(int op, const float* xyz_aos, const float* x, const float* y
                 int dev = 0;
                 (void)hipGetDevice(&dev);
                 // the workspace starts with one count per segment
-                if (tab) g_tol_last = TolLast{dev, w, lrm_tol_tab_segments(n), n, (uint32_t)LRM_TOL_TAB_SEG_CAP};
+                if (tab) g_tol_last = TolLast{dev, w, lrm_tol_tab_segments(n, mode == LRM_MODE_TOL_REL), n, (uint32_t)LRM_TOL_TAB_SEG_CAP};
                 else g_tol_last = TolLast{dev, w, lrm_tol_queue_words(n) / (4 * LRM_TOL_SEG_CAP_WORDS + 4), n, (uint32_t)LRM_TOL_SEG_CAP_WORDS};
                 return LRM_OK;
             }
@@ -1153,6 +1176,39 @@ int lrm_dbg_replay_host(const float* xyz, size_t n, const LrmLegDimensions* leg,
     }
     return LRM_OK;
 }
+// The plane table of (leg, quat) as the host builder (device = 0) or the device builder (device = 1, on the current device) makes
+// it: the table's bytes into out[cap] (when it fits), its size, the build's milliseconds.  LRM_EINVAL when the leg has no table.
+int lrm_dbg_toltab_build(const LrmLegDimensions* leg, const float* quat, int device, uint8_t* out, size_t cap, size_t* size_out, float* ms_out) {
+    if (!leg || !size_out) return fail(LRM_EINVAL, "null argument");
+    LrmCompiledLeg L;
+    lrm_compile_leg(*leg, quat_or_default(quat), 1, &L);
+    LrmTolLeg TL;
+    lrm_compile_tol(L, &TL);
+    if (!TL.tol_ok) return fail(LRM_EINVAL, "leg not eligible for the table-guided modes");
+    if (!device) {
+        std::vector<uint8_t> tab;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!lrm_build_tol_tab(TL, &tab)) return fail(LRM_EINVAL, "leg needs more table rows than a cell code can name");
+        if (ms_out) *ms_out = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *size_out = tab.size();
+        if (out && cap >= tab.size()) std::memcpy(out, tab.data(), tab.size());
+        return LRM_OK;
+    }
+    uint8_t* t = nullptr;
+    size_t bytes = 0;
+    float ms = 0.f;
+    const int rc = lrm_build_tol_tab_dev(TL, nullptr, &t, &bytes, &ms);
+    if (rc < 0) return hip_fail((hipError_t)(-rc), "plane table (device build)");
+    if (rc == 1) return fail(LRM_EINVAL, "leg needs more table rows than a cell code can name");
+    if (rc == 2) return fail(LRM_EINVAL, "the device builder declines this leg (too many unanswered cells)");
+    *size_out = bytes;
+    if (ms_out) *ms_out = ms;
+    hipError_t e = hipSuccess;
+    if (out && cap >= bytes) e = hipMemcpy(out, t, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(t);
+    HIP_TRY(e, "hipMemcpy plane table");
+    return LRM_OK;
+}
 // The table's lower bound of the in-plane distance at plane points (x = abscissa - coxa_length, z) of the INNER grid, next
 // to what the full plane evaluation (lrm_tol_plane) finds there: tests/test_tol_cpu.py checks bound <= distance.
 int lrm_dbg_toltab_bounds(const float* xz, size_t n, const LrmLegDimensions* leg, const float* quat, float* lb_out,
@@ -1595,6 +1651,7 @@ void lrm_release_workspaces(void) {
         host_pipe_free(hp.second);
     }
     g_host_pipe.clear();
+    lrm_toltab_dev_release();
     multi_release();
     if (have) (void)hipSetDevice(cur);
 }

@@ -31,3 +31,8 @@ bool lrm_build_tol_tab(const LrmTolLeg& L, std::vector<uint8_t>* out);
 
 // order[k] = index of the k-th point of the AoS cloud along a Morton (Z) curve over its bounding box (lrm_capi.cpp)
 void lrm_host_morton_order(const float* xyz_aos, size_t n, std::vector<size_t>* order);
+
+// ---- shared pieces of the two table builders (lrm_toltab.cpp; lrm_toltab_dev.hip uses them on the host side of its build) ----
+struct LrmTbInput;
+bool lrm_tb_number_rows(const LrmTbInput& in, uint64_t used_rows, uint32_t used_vrows, uint8_t* row_num, uint8_t* vrow_num, LrmTolTabHeader* hd);
+void lrm_tb_layout(const uint32_t n_fine[2], LrmTolTabHeader* hd, size_t* n_cells);

@@ -36,7 +36,7 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
                                uint32_t* workspace, uint32_t flags, hipStream_t st);
 // Table variant (dist_tab_kernel + the same fix-up): tab_dev = device copy of lrm_build_tol_tab's table for TL.
 size_t lrm_tol_tab_queue_words(size_t n);
-size_t lrm_tol_tab_segments(size_t n); // the workspace starts with one count per segment
+size_t lrm_tol_tab_segments(size_t n, bool rel); // the workspace starts with one count per segment (rel: LRM_MODE_TOL_REL's grid)
 struct LrmXtabLeg; // lrm_point_xtab.h
 hipError_t lrm_launch_dist_tab(int op, const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L,
                                const LrmTolLeg& TL, const LrmXtabLeg& X, const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy,
@@ -73,3 +73,8 @@ hipError_t lrm_launch_sweep_update(const uint8_t* all_legs, const uint8_t* cyl_v
                                    int use_culls, size_t nb, uint8_t* active, uint8_t* accepted, hipStream_t st);
 // evaluation counters of reach_any_wave_kernel in a -DLRM_PAIR_COUNT build (read and reset); hipErrorNotSupported otherwise
 hipError_t lrm_pair_counts(unsigned long long out[4]);
+
+// The plane table built on the device (lrm_toltab_dev.hip): 0 ok (*tab_dev_out = a fresh hipMalloc-ed table, the caller's), 1 this
+// leg has no table, 2 the device builder does not take this leg (use lrm_build_tol_tab), < 0 a negated hipError_t.
+int lrm_build_tol_tab_dev(const LrmTolLeg& L, hipStream_t st, uint8_t** tab_dev_out, size_t* bytes_out, float* ms_out);
+void lrm_toltab_dev_release();

@@ -328,13 +328,24 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
 #ifndef LRM_TAB_GRID_MULT
 #define LRM_TAB_GRID_MULT 8
 #endif
+#ifndef LRM_TAB_PREFETCH2
+#define LRM_TAB_PREFETCH2 0 // two rounds of loads in flight per wave (6 waves/SIMD): 80 / 123 / 933 us at 1e7 / 1.25e7 / 1e8 points against 75 / 119 / 891 (profiles/r04_ab_prefetch_nt.txt)
+#endif
+#ifndef LRM_TAB_NT_STORE
+#define LRM_TAB_NT_STORE 1 // the distance field is written once and never read by the kernels: non-temporal stores.  Nothing at 1e7 points (71.7 -> 70.8 us:
+                           // inputs and outputs fit the 256 MiB Infinity Cache together) or 1e8 (822 -> 827), but the 1.25e7-point share of the 1e8 cloud --
+                           // 312 MB cycling through a 256 MiB cache -- 117.7 -> 85.9 us: ordinary stores evict the inputs the next step re-reads
+#endif
+#ifndef LRM_TAB_NT_LOAD
+#define LRM_TAB_NT_LOAD 0 // non-temporal loads of the points as well: 72 -> 89 / 91 -> 109 / 800 -> 809 us at 1e7 / 1.25e7 / 1e8 points: no
+#endif
 struct TabLds {
     LrmTabRow rows[32];
     LrmTabVRow vrows[32];
 };
 constexpr int kTabSegCap = LRM_TOL_TAB_SEG_CAP; // doubt slots per workgroup of dist_tab_kernel
 #ifndef LRM_SHORT_CAP
-#define LRM_SHORT_CAP 24 // LDS slots per wave for the short vectors of LRM_MODE_TOL_REL (~8 expected over a wave's life; a record without room joins the doubt queue)
+#define LRM_SHORT_CAP 32 // LDS slots per wave for the short vectors of LRM_MODE_TOL_REL (~15 expected over a wave's five rounds; a record without room joins the doubt queue)
 #endif
 constexpr int kShortCap = LRM_SHORT_CAP;
 constexpr int kTabBoundVecs = LRM_TT_NB * LRM_TT_NB * 4 / 16; // 16-byte pieces of the inner grid's bounds
@@ -356,12 +367,20 @@ __global__ __launch_bounds__(kBlock, kShort ? LRM_TAB_MIN_WAVES - 1 : LRM_TAB_MI
     const LrmTolLeg& L = lrm_kernarg<LrmTolLeg>(kTolLegArg);
     const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
     LrmVec3 p_next{0.f, 0.f, 0.f}; // the first point in front of the table staging
+#if LRM_TAB_PREFETCH2
+    LrmVec3 p_next2{0.f, 0.f, 0.f}; // and the second round's: two rounds of loads in flight per wave (clouds beyond the Infinity Cache wait for HBM)
+#endif
     {
         const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x;
         const size_t rb0 = (size_t)blockIdx.x * kBlock;
         const uint32_t to = lrm_opaque(threadIdx.x * 4u);
         if (i0 < n) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb0, 3u * to), lrm_at(x + 3 * rb0, 3u * to + 4u), lrm_at(x + 3 * rb0, 3u * to + 8u)}
                                   : LrmVec3{lrm_at(x + rb0, to), lrm_at(y + rb0, to), lrm_at(z + rb0, to)};
+#if LRM_TAB_PREFETCH2
+        const size_t rb1 = rb0 + (size_t)gridDim.x * kBlock;
+        if (i0 + gridDim.x * kBlock < n) p_next2 = kAoS ? LrmVec3{lrm_at(x + 3 * rb1, 3u * to), lrm_at(x + 3 * rb1, 3u * to + 4u), lrm_at(x + 3 * rb1, 3u * to + 8u)}
+                                                       : LrmVec3{lrm_at(x + rb1, to), lrm_at(y + rb1, to), lrm_at(z + rb1, to)};
+#endif
     }
     {
         static_assert(sizeof(TabLds) == sizeof(hd->rows) + sizeof(hd->vrows) && sizeof(TabLds) % 16 == 0, "rows | vrows");
@@ -395,13 +414,29 @@ __global__ __launch_bounds__(kBlock, kShort ? LRM_TAB_MIN_WAVES - 1 : LRM_TAB_MI
         const size_t rbase = (size_t)blockIdx.x * kBlock + (size_t)round * stride;
         const uint32_t toff = lrm_opaque(toff0), tid_o = lrm_opaque(threadIdx.x);
         LrmVec3 p = p_next;
+#if LRM_TAB_PREFETCH2
+        {   // the points of the next two rounds are in flight while this one is evaluated
+            const uint32_t i_next = i + 2u * stride;
+            const size_t rb_next = rbase + 2 * (size_t)stride;
+            p_next = p_next2;
+            p_next2 = LrmVec3{0.f, 0.f, 0.f};
+            if (i_next < n32 && i_next > i) p_next2 = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
+                                                          : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
+        }
+#else
         {   // the next round's point is in flight while this one is evaluated
             const uint32_t i_next = i + stride;
             const size_t rb_next = rbase + stride;
             p_next = LrmVec3{0.f, 0.f, 0.f};
+#if LRM_TAB_NT_LOAD
+            if (i_next < n32) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
+                                          : LrmVec3{__builtin_nontemporal_load(&lrm_at(x + rb_next, toff)), __builtin_nontemporal_load(&lrm_at(y + rb_next, toff)), __builtin_nontemporal_load(&lrm_at(z + rb_next, toff))};
+#else
             if (i_next < n32) p_next = kAoS ? LrmVec3{lrm_at(x + 3 * rb_next, 3u * toff), lrm_at(x + 3 * rb_next, 3u * toff + 4u), lrm_at(x + 3 * rb_next, 3u * toff + 8u)}
                                           : LrmVec3{lrm_at(x + rb_next, toff), lrm_at(y + rb_next, toff), lrm_at(z + rb_next, toff)};
+#endif
         }
+#endif
         uint32_t doubt = 0;
         const LrmVec3 p_in = p; // kept for the queue record (three registers; re-loading it cost a pushing wave an L2 round trip)
         uint32_t info = 0; // kShort: what the evaluation decided (the fix-up replays the winner's value chain from it)
@@ -419,9 +454,15 @@ __global__ __launch_bounds__(kBlock, kShort ? LRM_TAB_MIN_WAVES - 1 : LRM_TAB_MI
                 lrm_at(dx + 3 * rbase, 3u * toff + 4u) = p.y;
                 lrm_at(dx + 3 * rbase, 3u * toff + 8u) = p.z;
             } else {
+#if LRM_TAB_NT_STORE // streaming stores of the field: see LRM_TAB_NT_STORE above
+                __builtin_nontemporal_store(p.x, &lrm_at(dx + rbase, toff));
+                __builtin_nontemporal_store(p.y, &lrm_at(dy + rbase, toff));
+                __builtin_nontemporal_store(p.z, &lrm_at(dz + rbase, toff));
+#else
                 lrm_at(dx + rbase, toff) = p.x;
                 lrm_at(dy + rbase, toff) = p.y;
                 lrm_at(dz + rbase, toff) = p.z;
+#endif
             }
             if (mask) lrm_at(mask + rbase, tid_o) = m;
         }
@@ -574,9 +615,15 @@ __global__ __launch_bounds__(kBlock, LRM_XTAB_MIN_WAVES) void dist_xtab_kernel(
                 lrm_at(dx + 3 * rbase, 3u * toff + 4u) = p.y;
                 lrm_at(dx + 3 * rbase, 3u * toff + 8u) = p.z;
             } else {
+#if LRM_TAB_NT_STORE
+                __builtin_nontemporal_store(p.x, &lrm_at(dx + rbase, toff));
+                __builtin_nontemporal_store(p.y, &lrm_at(dy + rbase, toff));
+                __builtin_nontemporal_store(p.z, &lrm_at(dz + rbase, toff));
+#else
                 lrm_at(dx + rbase, toff) = p.x;
                 lrm_at(dy + rbase, toff) = p.y;
                 lrm_at(dz + rbase, toff) = p.z;
+#endif
             }
             if (mask) lrm_at(mask + rbase, tid_o) = m;
         }
@@ -849,21 +896,37 @@ hipError_t lrm_launch_dist_tol(int op, const float* x, const float* y, const flo
 #ifndef LRM_TAB_FIX_BLOCK_REL
 #define LRM_TAB_FIX_BLOCK_REL 256 // of 256 threads: two passes of 128 points
 #endif
-static size_t tab_main_blocks(size_t n) {
-    const size_t base = (size_t)256 * LRM_TAB_MIN_WAVES * LRM_TAB_GRID_MULT; // workgroups of four waves: every resident slot LRM_TAB_GRID_MULT times over
+// Workgroups of the table kernels for n points.  Every workgroup runs the SAME number of rounds (a grid that is not a divisor of
+// the cloud leaves a ragged last round: the 1.25e7-point share of the 1e8 cloud ran 3.4 rounds on 14 336 workgroups and took 11.4 ps
+// per point against 9.9 for the whole 1e8, profiles/r03_tol_clouds.txt): rounds = what the base grid (every resident slot
+// LRM_TAB_GRID_MULT times over) needs, at most LRM_TAB_ROUNDS (a workgroup's doubt segment holds 17 % of LRM_TAB_ROUNDS rounds),
+// at least `min_rounds`; blocks = ceil(need / rounds).
+static size_t tab_blocks(size_t n, size_t min_rounds) {
+    const size_t base = (size_t)256 * LRM_TAB_MIN_WAVES * LRM_TAB_GRID_MULT; // workgroups of four waves
     const size_t need = (n + kBlock - 1) / kBlock;
-    size_t blocks = std::max(base, (need + LRM_TAB_ROUNDS - 1) / LRM_TAB_ROUNDS);
-    if (blocks > need) blocks = need;
-    if (blocks == 0) blocks = 1;
+    if (need <= 1) return 1;
+    size_t rounds = (need + base - 1) / base;
+    if (rounds > LRM_TAB_ROUNDS) rounds = LRM_TAB_ROUNDS;
+    if (rounds < min_rounds) rounds = min_rounds;
+    size_t blocks = (need + rounds - 1) / rounds;
+    const size_t floor_blocks = std::min(need, (size_t)2048); // small clouds: never fewer workgroups than fill the chip
+    if (blocks < floor_blocks) blocks = floor_blocks;
     return blocks;
 }
-size_t lrm_tol_tab_queue_words(size_t n) { return tab_main_blocks(n) * (4 * (size_t)kTabSegCap + 4); } // counts (padded to 16 bytes per workgroup) | 16-byte records
-size_t lrm_tol_tab_segments(size_t n) { return tab_main_blocks(n); }
+static size_t tab_main_blocks(size_t n) { return tab_blocks(n, 1); }
+// LRM_MODE_TOL_REL: LRM_SHORT_ROUNDS rounds per workgroup, so that its short vectors (4-5 % of a random cloud) about fill the one
+// wave that replays them at the end (with three rounds that wave ran half empty: 46 of the step's 407 VALU instructions per point)
+#ifndef LRM_SHORT_ROUNDS
+#define LRM_SHORT_ROUNDS 5
+#endif
+static size_t tab_short_blocks(size_t n) { return tab_blocks(n, LRM_SHORT_ROUNDS); }
+size_t lrm_tol_tab_queue_words(size_t n) { return tab_main_blocks(n) * (4 * (size_t)kTabSegCap + 4); } // counts (padded to 16 bytes per workgroup) | 16-byte records; (tab_main_blocks >= tab_short_blocks)
+size_t lrm_tol_tab_segments(size_t n, bool rel) { return rel ? tab_short_blocks(n) : tab_main_blocks(n); }
 template <int kOp, bool kAoS>
 static hipError_t launch_tab(const float* x, const float* y, const float* z, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, const LrmXtabLeg& X,
                              const uint8_t* tab_dev, uint8_t* mask, uint64_t* bits, float* dx, float* dy, float* dz, uint32_t* workspace,
                              uint32_t flags, hipStream_t st) {
-    const size_t blocks = tab_main_blocks(n);
+    const size_t blocks = (flags & LRM_TOLF_SHORT) ? tab_short_blocks(n) : tab_main_blocks(n);
     uint32_t* counts = workspace;
     QueueRec* queue = reinterpret_cast<QueueRec*>(workspace + 4 * blocks); // 16-byte aligned behind the counts
     if (flags & LRM_TOLF_SHORT)
