@@ -8,8 +8,8 @@ import os
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # every file the timed kernels are compiled from (the .hip translation units and the headers they include)
-KERNEL_SOURCES = ("lrm_tol_kernels.hip", "lrm_point_tol.h", "lrm_kernels.hip", "lrm_point_fast.h", "lrm_point.h",
-                  "lrm_exact_math.h", "lrm_types.h", "lrm_launch.h", "lrm_toltab.cpp", "Makefile")
+KERNEL_SOURCES = ("lrm_tol_kernels.hip", "lrm_point_tol.h", "lrm_point_xtab.h", "lrm_kernels.hip", "lrm_point_fast.h", "lrm_point.h",
+                  "lrm_exact_math.h", "lrm_types.h", "lrm_launch.h", "lrm_toltab.cpp", "lrm_toltab_build.h", "lrm_toltab_dev.hip", "Makefile")
 
 
 def kernel_src_sha():

@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh r02 [mode]
 # kernel stats of the default bench under rocprofv3, the three PMC passes, the un-profiled bench lines.
 set -o pipefail
-tag=${1:-r02}; mode=${2:-tol}
+tag=${1:-r04}; mode=${2:-tol_rel}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -17,6 +17,6 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCL
 echo "pmc passes done"
 cd $root
 python3 legged-robot-movability-cuda_amd/tools/summarize_profiles.py $out/pmc 10000000 $mode $out/$tag
-cp $out/${tag}_hbm_traffic.json $out/${tag}_valu.json profiles/ 2>/dev/null
+
 python3 bench.py --mode $mode > $out/bench.json 2> $out/bench.err
 echo "bench done"

@@ -24,7 +24,8 @@ from srchash import kernel_src_sha  # noqa: E402  (the tree the passes were coll
 STEP_KERNELS = {
     # whichever main kernel the build launches (the second template argument is the layout: false = one array per component)
     "tol": ["dist_tab_kernel<2, false, false>", "dist_tab_kernel<2, false>", "dist_tol_staged_kernel<2, false>", "dist_tol_staged_kernel<2>", "dist_tol_kernel<2>", "tol_fixup_kernel<2, false, 8, 128>", "tol_fixup_kernel<2, false, 8>", "tol_fixup_kernel<2, false>", "tol_fixup_kernel<2>"],
-    "fast": ["dist_soa_kernel<2, true>"],
+    "tol_rel": ["dist_tab_kernel<2, false, true>", "tol_fixup_kernel<2, false, 8, 128>"],
+    "fast": ["dist_xtab_kernel<2, false>", "tol_fixup_kernel<2, false, 8, 128>", "dist_soa_kernel<2, true>"],
     "strict": ["dist_soa_kernel<2, false>"],
 }
 
