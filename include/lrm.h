@@ -38,11 +38,15 @@ extern "C" {
  * LRM_MODE_STRICT: reference operation order, no FMA contraction, glibc-exact atan2f/sincosf:
  *                  bit-identical to the reference's host path (reachability_kernel_cpu /
  *                  distance_kernel_cpu, one_leg_global.cu:132-147).
- * LRM_MODE_FAST:   filtered evaluation (csrc/lrm_point_fast.h): decisions are taken with cheap
- *                  arithmetic plus conservative error bands, values that reach an output are
- *                  computed with the strict arithmetic, and any decision inside its band is
- *                  re-taken by the strict code: outputs are bit-identical to LRM_MODE_STRICT.
- *                  Legs outside the filter's eligibility silently use the strict kernels. */
+ * LRM_MODE_FAST:   the same outputs, bit for bit, faster.  Clouds of >= 2e5 points on legs with a plane table:
+ *                  csrc/lrm_point_xtab.h -- every DECISION (clamp target, validity, which yaw candidate) comes
+ *                  from the plane table of the tolerance mode with its error bands, every VALUE from the
+ *                  reference's own operations in its own order (one exact atan2f, one exact sincosf and one strict
+ *                  clamp per evaluated candidate); a point with a decision inside its band is re-evaluated by the
+ *                  filtered code in a second small launch.  Otherwise the filtered evaluation
+ *                  (csrc/lrm_point_fast.h): decisions with cheap arithmetic plus conservative bands, values that
+ *                  reach an output with the strict arithmetic, a decision inside its band re-taken by the strict
+ *                  code.  Legs outside the filter's eligibility silently use the strict kernels. */
 #define LRM_MODE_STRICT 0
 #define LRM_MODE_FAST 1
 /* LRM_MODE_TOL:    contract-tolerance mode (csrc/lrm_point_tol.h): the reach mask and the distance's
@@ -66,13 +70,14 @@ extern "C" {
  *                  LRM_MODE_FAST. */
 #define LRM_MODE_TOL 2
 /* LRM_MODE_TOL_REL: LRM_MODE_TOL with the LITERAL bound of BASELINE.json on every vector: reach mask and validity byte
- *                  bit-identical, |d - d_ref| <= 1e-5 |d_ref| for every point.  The tolerance kernels queue, next to their
- *                  doubtful points, every point whose vector comes out shorter than max(17 mm, 0.03 (|p|_1 + body)) -- the absolute
- *                  error of the tolerance arithmetic grows with the coordinates --; the fix-up launch computes those
- *                  with the LRM_MODE_FAST code, bit for bit (relative error 0).  Every longer vector is within 1e-5 relative
- *                  by LRM_MODE_TOL's own arithmetic (measured 7e-6 at most from 16 mm on; asserted: tests/test_gpu_tol.py).
- *                  About 4 % of a cloud filling the leg's bounding cube is re-evaluated (0.5 % in LRM_MODE_TOL); a cloud that
- *                  hugs the workspace's surface is re-evaluated whole and runs at LRM_MODE_FAST's speed. */
+ *                  bit-identical, |d - d_ref| <= 1e-5 |d_ref| for every point.  A vector that comes out shorter than
+ *                  max(17 mm, 0.03 (|p|_1 + body)) -- the absolute error of the tolerance arithmetic grows with the coordinates --
+ *                  has its value chain recomputed with the reference's own operations from the decisions the tolerance
+ *                  evaluation took (csrc/lrm_point_xtab.h: lrm_xtab_replay, inside the same kernel: bit-identical, relative
+ *                  error 0).  Every longer vector is within 1e-5 relative by LRM_MODE_TOL's own arithmetic (measured 7e-6 at
+ *                  most from 16 mm on; asserted: tests/test_gpu_tol.py).  About 5 % of a cloud filling the leg's bounding cube
+ *                  is replayed (+ the 0.5 % of doubtful points of LRM_MODE_TOL through the fix-up launch); a cloud that hugs the
+ *                  workspace's surface is replayed whole and runs at about half the speed.  The bench headline. */
 #define LRM_MODE_TOL_REL 3
 
 /* LegDimensions, HeaderCPP.h:19-52: 14 x f32 = 56 bytes, this field order. */

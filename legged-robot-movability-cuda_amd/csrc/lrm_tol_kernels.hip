@@ -328,6 +328,9 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
 #ifndef LRM_TAB_GRID_MULT
 #define LRM_TAB_GRID_MULT 8
 #endif
+#ifndef LRM_SHORT_MIN_WAVES
+#define LRM_SHORT_MIN_WAVES 5 // LRM_MODE_TOL_REL's variant carries the info word, the in-loop flush and the replay tail: 96 VGPRs; at 6 waves 12 bytes of scratch per lane
+#endif
 #ifndef LRM_TAB_PREFETCH2
 #define LRM_TAB_PREFETCH2 0 // two rounds of loads in flight per wave (6 waves/SIMD): 80 / 123 / 933 us at 1e7 / 1.25e7 / 1e8 points against 75 / 119 / 891 (profiles/r04_ab_prefetch_nt.txt)
 #endif
@@ -345,14 +348,16 @@ struct TabLds {
 };
 constexpr int kTabSegCap = LRM_TOL_TAB_SEG_CAP; // doubt slots per workgroup of dist_tab_kernel
 #ifndef LRM_SHORT_CAP
-#define LRM_SHORT_CAP 32 // LDS slots per wave for the short vectors of LRM_MODE_TOL_REL (~15 expected over a wave's five rounds; a record without room joins the doubt queue)
+#define LRM_SHORT_CAP 64 // LDS slots per wave for the short vectors of LRM_MODE_TOL_REL (~15 expected over a wave's five rounds; a segment without room for a round's records is replayed on the spot)
 #endif
 constexpr int kShortCap = LRM_SHORT_CAP;
+static_assert(kShortCap >= 64, "an emptied segment holds one round of a wave");
+__device__ __forceinline__ void wave_lds_fence_tol() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 constexpr int kTabBoundVecs = LRM_TT_NB * LRM_TT_NB * 4 / 16; // 16-byte pieces of the inner grid's bounds
 static_assert(kTabBoundVecs % kBlock == 0, "every thread stages the same number of pieces");
 // kShort: LRM_MODE_TOL_REL (a template argument: as a run-time flag the compiler computes the norm for every point of every mode)
 template <int kOp, bool kAoS = false, bool kShort = false>
-__global__ __launch_bounds__(kBlock, kShort ? LRM_TAB_MIN_WAVES - 1 : LRM_TAB_MIN_WAVES) void dist_tab_kernel( // (kShort carries the info word and the replay tail: spills at 7 waves)
+__global__ __launch_bounds__(kBlock, kShort ? LRM_SHORT_MIN_WAVES : LRM_TAB_MIN_WAVES) void dist_tab_kernel( // (kShort carries the info word and the replay tail: spills at 7 waves)
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, size_t n,
     const LrmTolLeg L_kernarg, const LrmXtabLeg X_kernarg, uint8_t* __restrict__ mask, uint64_t* __restrict__ bits, float* __restrict__ dx,
     float* __restrict__ dy, float* __restrict__ dz, const uint8_t* __restrict__ tab, QueueRec* __restrict__ queue,
@@ -400,6 +405,27 @@ __global__ __launch_bounds__(kBlock, kShort ? LRM_TAB_MIN_WAVES - 1 : LRM_TAB_MI
 #if defined(LRM_FIX_TRACE)
     if (threadIdx.x == 0 && blockIdx.x < 32768) g_main_trace[blockIdx.x * 2] = wall_clock64();
 #endif
+    // LRM_MODE_TOL_REL: records [k, count) of a segment, one lane each: the tolerance evaluation took every DECISION for them (none
+    // in doubt); lrm_xtab_replay recomputes the winner's VALUE chain with the reference's own operations (no table look-ups, no
+    // bands): these vectors are bit-identical to the reference's.
+    const LrmXtabLeg& X = lrm_kernarg<LrmXtabLeg>(kTolLegArg + (unsigned)sizeof(LrmTolLeg));
+    auto replay_records = [&](const uint32_t* segment, uint32_t count, uint32_t k) {
+        if (k < count) {
+            const uint32_t* r = segment + 5u * k;
+            const size_t i = r[0];
+            LrmVec3 q{lrm_u2f(r[1]), lrm_u2f(r[2]), lrm_u2f(r[3])};
+            lrm_xtab_replay(lrm_fresh(X), s_tab.rows, q, r[4]);
+            if (kAoS) {
+                dx[3 * i] = q.x;
+                dx[3 * i + 1] = q.y;
+                dx[3 * i + 2] = q.z;
+            } else {
+                dx[i] = q.x;
+                dy[i] = q.y;
+                dz[i] = q.z;
+            }
+        }
+    };
     const uint32_t stride = gridDim.x * kBlock;
     const uint32_t n_pad = (uint32_t)((n + 63) & ~(size_t)63); // whole waves iterate together (ballots below)
     const uint32_t n32 = (uint32_t)n; // the C ABI sends clouds of 0xc0000000 points and more to the bit-exact kernels: indices fit 32 bits
@@ -477,18 +503,26 @@ __global__ __launch_bounds__(kBlock, kShort ? LRM_TAB_MIN_WAVES - 1 : LRM_TAB_MI
 #else
             if (sm) {
 #endif
-                const uint32_t qs = wq + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
-                if (is_short) {
-                    if (qs < (uint32_t)kShortCap) {
-                        uint32_t* r = s_short + 5u * (wave_s * (uint32_t)kShortCap + qs);
-                        r[0] = i;
-                        r[1] = lrm_f2u(p_in.x);
-                        r[2] = lrm_f2u(p_in.y);
-                        r[3] = lrm_f2u(p_in.z);
-                        r[4] = info;
-                    } else doubt = 1u;
+                // A segment without room for this round's records is replayed on the spot by its own wave (a cloud of reachable
+                // points only has 35 % short vectors: sending what does not fit to the doubt queue made its workgroups overflow and
+                // the filtered code redo them whole, 0.71 ms per 1e7 points; profiles/r04_bench_a.json).  The earlier stores of the
+                // same points came from this wave: they are complete before the replayed ones go out.
+                if (wq + (uint32_t)__popcll(sm) > (uint32_t)kShortCap) { // wave-uniform
+                    __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores have reached the L2
+                    replay_records(s_short + 5u * wave_s * (uint32_t)kShortCap, wq, (uint32_t)lane);
+                    wave_lds_fence_tol();
+                    wq = 0;
                 }
-                wq = min(wq + (uint32_t)__popcll(sm), (uint32_t)kShortCap);
+                const uint32_t qs = wq + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+                if (is_short) { // (at most 64 records per round, kShortCap >= 64: they fit)
+                    uint32_t* r = s_short + 5u * (wave_s * (uint32_t)kShortCap + qs);
+                    r[0] = i;
+                    r[1] = lrm_f2u(p_in.x);
+                    r[2] = lrm_f2u(p_in.y);
+                    r[3] = lrm_f2u(p_in.z);
+                    r[4] = info;
+                }
+                wq += (uint32_t)__popcll(sm);
             }
         }
         const uint64_t dm = __ballot(doubt != 0); // queue A: per-workgroup segment, slots from an LDS counter
@@ -506,31 +540,14 @@ __global__ __launch_bounds__(kBlock, kShort ? LRM_TAB_MIN_WAVES - 1 : LRM_TAB_MI
     __syncthreads(); // (also orders this workgroup's stores of the tolerance vectors before the replayed ones below)
     if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
     if (kShort) {
-        // ---- the tail: the workgroup's short vectors, compacted over its waves' segments, one lane per record.  The tolerance
-        // evaluation took every DECISION for them (none in doubt); lrm_xtab_replay recomputes the winner's VALUE chain with the
-        // reference's own operations (no table look-ups, no bands): these vectors are bit-identical to the reference's. ----
-        const LrmXtabLeg& X = lrm_kernarg<LrmXtabLeg>(kTolLegArg + (unsigned)sizeof(LrmTolLeg));
+        // ---- the tail: what is left in the four segments, compacted over the workgroup's waves (usually its first wave alone) ----
         static_assert(kBlock / 64 == 4, "four wave segments");
         const uint32_t c0 = s_wcnt[0], c1 = c0 + s_wcnt[1], c2 = c1 + s_wcnt[2], total = c2 + s_wcnt[3];
-        for (uint32_t k0 = wave_s * 64u; k0 < total; k0 += (uint32_t)kBlock) { // wave-uniform: usually only the first wave has work
+        for (uint32_t k0 = wave_s * 64u; k0 < total; k0 += (uint32_t)kBlock) { // wave-uniform
             const uint32_t k = k0 + (uint32_t)lane;
-            if (k < total) {
-                const uint32_t w = (k >= c0 ? 1u : 0u) + (k >= c1 ? 1u : 0u) + (k >= c2 ? 1u : 0u);
-                const uint32_t first = w == 0u ? 0u : (w == 1u ? c0 : (w == 2u ? c1 : c2));
-                const uint32_t* r = s_short + 5u * (w * (uint32_t)kShortCap + (k - first));
-                const size_t i = r[0];
-                LrmVec3 q{lrm_u2f(r[1]), lrm_u2f(r[2]), lrm_u2f(r[3])};
-                lrm_xtab_replay(lrm_fresh(X), s_tab.rows, q, r[4]);
-                if (kAoS) {
-                    dx[3 * i] = q.x;
-                    dx[3 * i + 1] = q.y;
-                    dx[3 * i + 2] = q.z;
-                } else {
-                    dx[i] = q.x;
-                    dy[i] = q.y;
-                    dz[i] = q.z;
-                }
-            }
+            const uint32_t w = (k >= c0 ? 1u : 0u) + (k >= c1 ? 1u : 0u) + (k >= c2 ? 1u : 0u);
+            const uint32_t first = w == 0u ? 0u : (w == 1u ? c0 : (w == 2u ? c1 : c2));
+            replay_records(s_short + 5u * w * (uint32_t)kShortCap, k < total ? (k - first) + 1u : 0u, k - first);
         }
     }
 #if defined(LRM_FIX_TRACE)

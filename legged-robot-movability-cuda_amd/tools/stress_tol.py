@@ -58,6 +58,7 @@ def main():
                                   float(rng.uniform(25, 85)), float(rng.uniform(50, 100)), float(rng.uniform(80, 140)),
                                   float(rng.uniform(-15, 10)), float(rng.uniform(-15, 10)))
         out["legs"] += 1
+        print(f"leg {li + 1} / {args.legs}: {out['evaluations']} evaluations so far, max error {out['max_err']:.3e}", file=sys.stderr, flush=True)  # (a sign of life for the job runner)
         reach = float(leg[1] + leg[3] + leg[4] + leg[5])  # body + coxa + tibia + femur lengths
         for qi in range(3):
             if qi == 0:
