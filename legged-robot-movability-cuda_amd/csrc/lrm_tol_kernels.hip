@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kBlock, LRM_TOL_MIN_WAVES) void dist_tol_staged_ker
 #define LRM_TAB_GRID_MULT 8
 #endif
 #ifndef LRM_SHORT_MIN_WAVES
-#define LRM_SHORT_MIN_WAVES 5 // LRM_MODE_TOL_REL's variant carries the info word, the in-loop flush and the replay tail: 96 VGPRs; at 6 waves 12 bytes of scratch per lane
+#define LRM_SHORT_MIN_WAVES 6 // LRM_MODE_TOL_REL's variant carries the info word, the in-loop flush and the replay tail: 80 VGPRs + 12 bytes of scratch per lane (the flush) at 6 waves: 92.2 us; 96 VGPRs at 5 waves: 96.2
 #endif
 #ifndef LRM_TAB_PREFETCH2
 #define LRM_TAB_PREFETCH2 0 // two rounds of loads in flight per wave (6 waves/SIMD): 80 / 123 / 933 us at 1e7 / 1.25e7 / 1e8 points against 75 / 119 / 891 (profiles/r04_ab_prefetch_nt.txt)
