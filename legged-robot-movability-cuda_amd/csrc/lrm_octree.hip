@@ -29,12 +29,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/lrm.h"
 #include "lrm_compile.h"
 #include "lrm_point.h"
 #include "lrm_point_fast.h"
+#include "lrm_point_tol.h"
 
 namespace {
 
@@ -66,8 +70,14 @@ __device__ __forceinline__ bool in_box(LrmVec3 v, float hx, float hy, float hz) 
 // item contributes `reach = parent_valid`, no edge -- without evaluating anything; and inside an item that is evaluated, the
 // legs beyond their own sphere are skipped (they neither reach nor cross).  Deep in the tree (small boxes, four
 // legs mounted 45 degrees apart) that is most of the footholds inside the elongated parent box.
+// `tols` (filtered mode, or null): the tolerance block of every (orientation, leg) (lrm_compile_tol).  The flags need the
+// distance's validity and whether its vector falls inside the child box -- DECISIONS, not the vector's last bits: the
+// contract-tolerance evaluation (lrm_dist_tol, lrm_point_tol.h: ~500 instructions instead of the filtered code's ~1000) answers
+// them unless one of its own decisions is in doubt or the vector ends within its error of a face of the box (of the sphere);
+// those few evaluations are redone by the filtered code.  Same flags either way (tests/test_gpu_octree.py).
 template <bool kFast>
 __device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 vect, float h2, float hd, const LrmCompiledLeg* __restrict__ legs,
+                                                   const LrmTolLeg* __restrict__ tols,
                                                    const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float convex_r2) {
     uint32_t mine = 0;
     for (int a = 0; a < ch.n_angles; a++) {
@@ -89,9 +99,33 @@ __device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 v
             if (!((near_bits >> l) & 1u)) continue; // beyond this leg's sphere: it neither reaches nor crosses (same argument)
             const LrmCompiledLeg& L = legs[a * leg_count + l];
             LrmVec3 v = vect;
-            bool sub;
-            if (kFast) sub = lrm_dist_global_filtered(L, LrmDistTables{&L.lists[0][0], &L.dist_tab[0][0], &L.corner_tab[0]}, v);
-            else sub = lrm_dist_global(L, &L.lists[0][0], v);
+            bool sub = false, done = false;
+            if (kFast && tols) {
+                const LrmTolLeg& TL = tols[a * leg_count + l];
+                if (TL.tol_ok) { // (wave-uniform)
+                    uint32_t dbt = 0;
+                    LrmVec3 tv = vect;
+                    const bool tsub = lrm_dist_tol(TL, LrmTolTables{&TL.circ[0][0], &TL.feat[0]}, tv, dbt);
+                    // the tolerance vector is within 1e-5 of max(|d|, (|p| + body) / 8) of the reference's (include/lrm.h): eps covers it twice
+                    const float eps = 2.0e-5f * (fabsf(tv.x) + fabsf(tv.y) + fabsf(tv.z) + fabsf(vect.x) + fabsf(vect.y) + fabsf(vect.z) + 400.f) + 1.0e-3f;
+                    bool near_face;
+                    if (h2 > convex_r2) {
+                        near_face = fabsf(fabsf(tv.x) - fabsf(ch.h[0])) < eps || fabsf(fabsf(tv.y) - fabsf(ch.h[1])) < eps || fabsf(fabsf(tv.z) - fabsf(ch.h[2])) < eps;
+                    } else {
+                        const float n = sqrtf(tv.x * tv.x + tv.y * tv.y + tv.z * tv.z), rr = sqrtf(fmaxf(h2 + ch.margin, 0.f));
+                        near_face = fabsf(n - rr) < eps;
+                    }
+                    if ((dbt & 0xffffu) == 0u && !near_face) {
+                        v = tv;
+                        sub = tsub;
+                        done = true;
+                    }
+                }
+            }
+            if (!done) {
+                if (kFast) sub = lrm_dist_global_filtered(L, LrmDistTables{&L.lists[0][0], &L.dist_tab[0][0], &L.corner_tab[0]}, v);
+                else sub = lrm_dist_global(L, &L.lists[0][0], v);
+            }
             bool cross;
             if (h2 > convex_r2) cross = in_box(v, ch.h[0], ch.h[1], ch.h[2]);   // :103-107 (margin unused there)
             else cross = (v.x * v.x + v.y * v.y + v.z * v.z) < h2 + ch.margin;  // :108-109
@@ -109,8 +143,8 @@ template <bool kFast>
 __global__ __launch_bounds__(kOctBlock) void oct_validity_kernel(
     const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
     const float* __restrict__ fy, const float* __restrict__ fz, size_t nf,
-    const LrmCompiledLeg* __restrict__ legs /* [n_angles_max][leg_count] */, const float4* __restrict__ spheres /* same shape */,
-    int leg_count, int legs_for_stab,
+    const LrmCompiledLeg* __restrict__ legs /* [n_angles_max][leg_count] */, const LrmTolLeg* __restrict__ tols /* same shape, or null */,
+    const float4* __restrict__ spheres /* same shape */, int leg_count, int legs_for_stab,
     float reach_len, float convex_r2, uint32_t* __restrict__ flags /* per child: 1 reach, 2 valid leaf, 4 edge */) {
     const OctChild ch = children[blockIdx.y];
     if (ch.skip) return;
@@ -132,7 +166,7 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_kernel(
         const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
         // elongated parent box, several_leg_octree.cu:76-82
         if (!in_box(vect, ch.ph[0] + reach_len, ch.ph[1] + reach_len, ch.ph[2] + reach_len)) continue;
-        mine |= oct_item_flags<kFast>(ch, vect, h2, hd, legs, spheres, leg_count, legs_for_stab, convex_r2);
+        mine |= oct_item_flags<kFast>(ch, vect, h2, hd, legs, tols, spheres, leg_count, legs_for_stab, convex_r2);
     }
     // wave OR, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) mine |= __shfl_xor(mine, off);
@@ -198,7 +232,7 @@ template <bool kFast>
 __global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
     const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
     const float* __restrict__ fy, const float* __restrict__ fz, size_t nf, const float* __restrict__ boxes, size_t ntiles,
-    const LrmCompiledLeg* __restrict__ legs, const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float reach_len,
+    const LrmCompiledLeg* __restrict__ legs, const LrmTolLeg* __restrict__ tols, const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float reach_len,
     float convex_r2, uint32_t* __restrict__ flags /* zeroed by the host */, uint32_t splits) {
     __shared__ uint32_t s_flags, s_ntiles, s_nchunks;
     __shared__ uint32_t s_tiles[kOctBlock];
@@ -246,7 +280,7 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
                 if (f < nf) {
                     const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
                     if (in_box(vect, ch.ph[0] + reach_len, ch.ph[1] + reach_len, ch.ph[2] + reach_len)) {
-                        mine = oct_item_flags<kFast>(ch, vect, h2, hd, legs, spheres, leg_count, legs_for_stab, convex_r2);
+                        mine = oct_item_flags<kFast>(ch, vect, h2, hd, legs, tols, spheres, leg_count, legs_for_stab, convex_r2);
                     }
                 }
                 for (int off = 32; off > 0; off >>= 1) mine |= __shfl_xor(mine, off);
@@ -506,6 +540,7 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
     uint32_t* d_keys = nullptr;
     void* d_sort_tmp = nullptr;
     float4* d_spheres = nullptr;
+    LrmTolLeg* d_tols = nullptr;
     LrmCompiledLeg* d_legs = nullptr;
     OctChild* d_children = nullptr;
     uint32_t* d_flags = nullptr;
@@ -520,6 +555,7 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
         if (d_sort_tmp) (void)hipFree(d_sort_tmp);
         if (d_legs) (void)hipFree(d_legs);
         if (d_spheres) (void)hipFree(d_spheres);
+        if (d_tols) (void)hipFree(d_tols);
         if (d_children) (void)hipFree(d_children);
         if (d_flags) (void)hipFree(d_flags);
         if (ev_a) (void)hipEventDestroy(ev_a);
@@ -602,6 +638,38 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
         }
     }
     const bool fast = all_fast && lrm_get_mode() != LRM_MODE_STRICT;
+    // the tolerance blocks (filtered mode; LRM_OCT_TOL=0: without -- A/B runs and tests): lrm_compile_tol costs ~0.3 ms of host
+    // geometry per (orientation, leg), so they are worth it from a few hundred thousand footholds on and are kept across calls
+    {
+        const char* e = getenv("LRM_OCT_TOL");
+        const bool want = fast && (e ? e[0] != '0' : nf >= 300000);
+        if (want) {
+            static std::mutex mu;
+            static std::map<std::array<float, 18>, LrmTolLeg> cache;
+            std::vector<LrmTolLeg> tols(legs.size());
+            std::lock_guard<std::mutex> g(mu);
+            for (int a = 0; a < n_angles_max; a++) {
+                const Quat q = quat_from_angle_index((unsigned)a, st);
+                for (int l = 0; l < st.leg_count; l++) {
+                    LrmLegDimensions leg = *dim;
+                    leg.body_angle = st.leg_mount[l];
+                    std::array<float, 18> key;
+                    std::memcpy(key.data(), &leg, 14 * sizeof(float));
+                    key[14] = q.x; key[15] = q.y; key[16] = q.z; key[17] = q.w;
+                    auto it = cache.find(key);
+                    if (it == cache.end()) {
+                        if (cache.size() >= 1024) cache.clear();
+                        LrmTolLeg tl;
+                        lrm_compile_tol(legs[(size_t)a * st.leg_count + l], &tl);
+                        it = cache.emplace(key, tl).first;
+                    }
+                    tols[(size_t)a * st.leg_count + l] = it->second;
+                }
+            }
+            OCT_TRY(hipMalloc(&d_tols, tols.size() * sizeof(LrmTolLeg)), "hipMalloc tolerance blocks");
+            OCT_TRY(hipMemcpy(d_tols, tols.data(), tols.size() * sizeof(LrmTolLeg), hipMemcpyHostToDevice), "hipMemcpy tolerance blocks");
+        }
+    }
     OCT_TRY(hipMalloc(&d_legs, legs.size() * sizeof(LrmCompiledLeg)), "hipMalloc legs");
     OCT_TRY(hipMemcpy(d_legs, legs.data(), legs.size() * sizeof(LrmCompiledLeg), hipMemcpyHostToDevice), "hipMemcpy legs");
     // bounding sphere of what each (orientation, leg) reaches, in the frame distance_global takes its point in:
@@ -713,10 +781,10 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
                 const dim3 grid((unsigned)std::min<size_t>(nc * splits, (size_t)256 * 64));
                 if (fast)
                     hipLaunchKernelGGL(oct_validity_chunked_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits);
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits);
                 else
                     hipLaunchKernelGGL(oct_validity_chunked_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits);
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits);
             } else {
                 // few, huge children (the first levels): every foothold, spread over the chip; grid.y = children < 65
                 size_t gx = (nf + kOctBlock - 1) / kOctBlock;
@@ -724,10 +792,10 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
                 const dim3 grid((unsigned)gx, (unsigned)nc);
                 if (fast)
                     hipLaunchKernelGGL(oct_validity_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+                                       d_f + 2 * nf, nf, d_legs, d_tols, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
                 else
                     hipLaunchKernelGGL(oct_validity_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_legs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+                                       d_f + 2 * nf, nf, d_legs, d_tols, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
             }
             OCT_TRY(hipGetLastError(), "Kernel launch");
             OCT_TRY(hipEventRecord(ev_b, nullptr), "hipEventRecord");

@@ -1,11 +1,12 @@
 #!/bin/bash
 # Collects the round's profile set on the GPU box into gpurun_out/rXX/ (run from the repository root):
-#   tools/collect_profiles.sh r02 [mode]
+#   tools/collect_profiles.sh r04 [mode] [suffix]     (suffix: e.g. _fast for a second mode's set -> gpurun_out/r04_fast/)
 # kernel stats of the default bench under rocprofv3, the three PMC passes, the un-profiled bench lines.
 set -o pipefail
 tag=${1:-r04}; mode=${2:-tol_rel}
 root=${GRAFT_REPO_ROOT:-$PWD}
-out=$root/gpurun_out/$tag
+suf=${3:-}
+out=$root/gpurun_out/$tag$suf
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --mode $mode --no-cpu-baseline --no-extras > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err

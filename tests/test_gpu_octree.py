@@ -8,9 +8,13 @@ from octree_oracle import apply_oct as oracle_apply_oct
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["strict", "fast"])
-def mode(request, lrm):
-    lrm.set_mode(lrm.MODE_FAST if request.param == "fast" else lrm.MODE_STRICT)
+@pytest.fixture(autouse=True, params=["strict", "fast", "fast_tol"])
+def mode(request, lrm, monkeypatch):
+    """strict: lrm_point.h verbatim; fast: the filtered code for every work item (LRM_OCT_TOL=0); fast_tol: the contract-tolerance
+    evaluation first, the filtered code for its doubts and for vectors that end near a face of the child box (LRM_OCT_TOL=1: whatever
+    the cloud's size; the library's default takes it from 3e5 footholds on).  All three must give the same leaves."""
+    lrm.set_mode(lrm.MODE_STRICT if request.param == "strict" else lrm.MODE_FAST)
+    monkeypatch.setenv("LRM_OCT_TOL", "1" if request.param == "fast_tol" else "0")
     yield request.param
     lrm.set_mode(lrm.MODE_FAST)
 
