@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 namespace {
 
@@ -405,19 +407,37 @@ namespace {
 // of the other three circles of its list: max_j sg_j (|q - c_j| - thr_j), q = c_i + r_i (cos th, sin th);
 // the clamp point passes multi_circle_validate (one_leg.cu:65-89) <=> the value is negative
 // (it is always valid for its own circle: |d| ~ 0 < CIRCLE_MARGIN).
-double clamp_validity(const LrmCircle* list, int i, double th) {
+double clamp_validity_dir(const LrmCircle* list, int i, double c, double s) { // (c, s) = the direction's cosine and sine
     const double margin = 0.001;
-    const double qx = (double)list[i].x + (double)list[i].r * std::cos(th);
-    const double qy = (double)list[i].y + (double)list[i].r * std::sin(th);
+    const double qx = (double)list[i].x + (double)list[i].r * c;
+    const double qy = (double)list[i].y + (double)list[i].r * s;
     double g = -1e300;
     for (int j = 0; j < LRM_N_CIRCLES; j++) {
         if (j == i) continue;
         const bool attract = list[j].attract != 0.f;
         const double thr = attract ? (double)list[j].r + margin : (double)list[j].r - margin;
-        const double mag = std::hypot(qx - (double)list[j].x, qy - (double)list[j].y);
+        const double ex = qx - (double)list[j].x, ey = qy - (double)list[j].y;
+        const double mag = std::sqrt(ex * ex + ey * ey);
         g = std::max(g, attract ? mag - thr : thr - mag);
     }
     return g;
+}
+double clamp_validity(const LrmCircle* list, int i, double th) { return clamp_validity_dir(list, i, std::cos(th), std::sin(th)); }
+// the directions of clamp_arc's safety net: the same 4096 for every circle of every leg
+constexpr int kArcSamples = 4096;
+struct ArcDirs {
+    double c[kArcSamples], s[kArcSamples];
+    ArcDirs() {
+        for (int k = 0; k < kArcSamples; k++) {
+            const double th = 6.283185307179586 * (k + 0.5) / kArcSamples;
+            c[k] = std::cos(th);
+            s[k] = std::sin(th);
+        }
+    }
+};
+const ArcDirs& arc_dirs() {
+    static const ArcDirs d; // (thread-safe initialisation)
+    return d;
 }
 
 // The directions for which the clamp point of circle i is valid, as ONE arc {u : u . m >= chw} when that is
@@ -545,12 +565,12 @@ bool clamp_arc(const LrmCircle* list, int i, double eps, double qa, double qb, L
         out->bw = (float)(w_band + 1e-6); // + the float evaluation of w itself (a few ulp of 1)
     }
     // safety net on a dense sample: the arc form agrees with the direct evaluation wherever that is certain
-    const int kSamples = 4096;
-    for (int s = 0; s < kSamples; s++) {
-        const double th = two_pi * (s + 0.5) / kSamples;
+    const ArcDirs& dirs = arc_dirs();
+    for (int s = 0; s < kArcSamples; s++) {
+        const double th = two_pi * (s + 0.5) / kArcSamples;
         if (!in_query(th)) continue;
-        const double g = clamp_validity(list, i, th);
-        const double w = (double)out->mx * std::cos(th) + (double)out->my * std::sin(th) - (double)out->chw;
+        const double g = clamp_validity_dir(list, i, dirs.c[s], dirs.s[s]);
+        const double w = (double)out->mx * dirs.c[s] + (double)out->my * dirs.s[s] - (double)out->chw;
         if (std::fabs(g) < eps) {
             if (!(std::fabs(w) < (double)out->bw)) TOL_REJECT("an uncertain direction outside the doubt band");
         } else if ((g < 0) != (w >= 0)) {
@@ -581,6 +601,7 @@ void lrm_compile_tol(const LrmCompiledLeg& L, LrmTolLeg* out) {
         q_lo[3] = mid;                 q_hi[3] = fs1;                // upper, fully extended
     }
     double r_outer = 0;
+    double qa_of[16], qb_of[16];
     for (int k = 0; k < 4; k++)
         for (int i = 0; i < LRM_N_CIRCLES; i++) {
             auto& c = out->circ[k][i];
@@ -593,10 +614,30 @@ void lrm_compile_tol(const LrmCompiledLeg& L, LrmTolLeg* out) {
                 qa = q_lo[k] - slack;
                 qb = std::max(q_hi[k], q_lo[k]) + slack; // an empty sector (never selected) keeps a token range
             }
-            if (ok || std::getenv("LRM_TOL_DEBUG")) ok = clamp_arc(L.lists[k], i, eps, qa, qb, &c) && ok;
+            qa_of[k * LRM_N_CIRCLES + i] = qa;
+            qb_of[k * LRM_N_CIRCLES + i] = qb;
             out->feat[k * LRM_N_CIRCLES + i] = ci;
             r_outer = std::max(r_outer, std::hypot((double)ci.x, (double)ci.y) + (double)ci.r);
         }
+    if (ok || std::getenv("LRM_TOL_DEBUG")) {
+        // the arcs of the sixteen (list, circle) pairs are independent (each intersects three caps and verifies its arc form on 4096
+        // directions: most of this function's ~1.5 ms): a few host threads; a caller that changes orientation per call pays this per call
+        bool arc_ok[16];
+        auto work = [&](int t, int nt) {
+            for (int j = t; j < 16; j += nt) arc_ok[j] = clamp_arc(L.lists[j / LRM_N_CIRCLES], j % LRM_N_CIRCLES, eps, qa_of[j], qb_of[j], &out->circ[j / LRM_N_CIRCLES][j % LRM_N_CIRCLES]);
+        };
+        int nt = (int)std::thread::hardware_concurrency();
+        nt = nt < 1 ? 1 : (nt > 4 ? 4 : nt);
+        if (std::getenv("LRM_TOL_DEBUG")) nt = 1; // (its messages in order)
+        if (const char* e = std::getenv("LRM_COMPILE_THREADS")) nt = std::max(1, std::atoi(e));
+        if (nt == 1) work(0, 1);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nt; t++) pool.emplace_back(work, t, nt);
+            for (auto& th : pool) th.join();
+        }
+        for (int j = 0; j < 16; j++) ok = arc_ok[j] && ok;
+    }
     // corner points: exact repeats are already gone; near-repeats (closer than 1e-4 mm: a tenth of the
     // smallest tie band) would put every point whose nearest target they are in doubt -- keep the first,
     // as the reference's strict "closer than" does for exact ties
