@@ -304,17 +304,34 @@ LRM_HD void lrm_xtab_replay(const LrmXtabLeg& X, const LrmTabRow* rows, LrmVec3&
     // an invalid DIRECT candidate inside the yaw range whose flipped candidate is mega-saturated onto it has a twin (lrm_xtab_point);
     // the strict comparisons of finish_finding_closest (one_leg.cu:219-220) on the flipped yaw
     const bool twinp = !flip && code == 0u && ((ang_flip > X.mega_hi) || (ang_flip < X.mega_lo));
+    const bool twin = twinp && !flag && (ang_ff != ang);
     const bool lim = code >= 2u, mn = code == 3u;
     const float angle = flip ? ang_flip : ang;
     const float limit = (angle > X.coxa_mid) ? X.max_coxa : X.min_coxa;
     const float sat = lim ? (mn ? X.min_coxa : X.max_coxa) : ((code == 1u) ? ang_flip : (flip ? ang_ff : ang));
     float s = mn ? X.lim_sc[2] : X.lim_sc[0], c = mn ? X.lim_sc[3] : X.lim_sc[1];
+    // This function is a latency chain run by one wave at the end of its workgroup (the workgroup's LDS and wave slots wait for it):
+    // the twin's value chain -- independent of the candidate's once the yaw is known -- is written next to it, not behind a branch,
+    // so that the two sincosf / clamp chains interleave (a wave of short vectors nearly always holds a lane that needs the twin).
+    float s1, c1;
     if (!lim) lrm_sincosf(-sat, &s, &c);
-    LrmVec3 q = a;
+    lrm_sincosf(-ang_ff, &s1, &c1);
+    LrmVec3 q = a, q1 = a;
     buffer = q.x * s; // cancel_coxa_rotation
     q.x = q.x * c - q.y * s;
     q.y = buffer + q.y * c;
-    if (off) { // the offset from the yaw-limit plane (one_leg.cu:258-274 decided `d_clamped > d_limit`)
+    float buffer1 = q1.x * s1;
+    q1.x = q1.x * c1 - q1.y * s1;
+    q1.y = buffer1 + q1.y * c1;
+    {   // the twin: force_clamp_on_circle onto the same target (lrm_xtab_twin, written out)
+        const float x1 = q1.x - X.coxa_length;
+        float cx = x1, cy = q1.z, d;
+        bool v;
+        lrm_clamp_on(t.x, t.y, t.r, true, cx, cy, d, v);
+        q1.x = x1 - cx;
+        q1.z = q1.z - cy;
+    }
+    if (LRM_TOL_ANY(off)) { // the offset from the yaw-limit plane (one_leg.cu:258-274 decided `d_clamped > d_limit`)
         const float th = -(limit - sat);
         float s2 = th, c2 = 1.0f;
         if (th != 0.f) lrm_sincosf(th, &s2, &c2);
@@ -323,8 +340,15 @@ LRM_HD void lrm_xtab_replay(const LrmXtabLeg& X, const LrmTabRow* rows, LrmVec3&
         const float b2 = l.y * s2;
         l.y = -l.x * s2 + l.y * c2;
         l.x = l.x * c2 + b2;
-        q = l;
-    } else { // force_clamp_on_circle onto the winner (one_leg.cu:42-63), (x, z) -= clamp point (:143-144)
+        // force_clamp_on_circle onto the winner (one_leg.cu:42-63), (x, z) -= clamp point (:143-144)
+        const float x = q.x - X.coxa_length;
+        float cx = x, cy = q.z, d;
+        bool v;
+        lrm_clamp_on(t.x, t.y, t.r, true, cx, cy, d, v);
+        q.x = off ? l.x : x - cx;
+        q.y = off ? l.y : q.y;
+        q.z = off ? l.z : q.z - cy;
+    } else {
         const float x = q.x - X.coxa_length;
         float cx = x, cy = q.z, d;
         bool v;
@@ -335,13 +359,14 @@ LRM_HD void lrm_xtab_replay(const LrmXtabLeg& X, const LrmTabRow* rows, LrmVec3&
     buffer = q.y * s; // restore_coxa_rotation
     q.y = -q.x * s + q.y * c;
     q.x = q.x * c + buffer;
-    const bool twin = twinp && !flag && (ang_ff != ang);
-    if (LRM_TOL_ANY(twin)) {
-        const LrmVec3 fb = lrm_xtab_twin(X, a, ang_ff, t.x, t.y, t.r);
-        const bool take = twin && !(lrm_norm3(q) < lrm_norm3(fb));
-        q.x = take ? fb.x : q.x;
-        q.y = take ? fb.y : q.y;
-        q.z = take ? fb.z : q.z;
+    buffer1 = q1.y * s1;
+    q1.y = -q1.x * s1 + q1.y * c1;
+    q1.x = q1.x * c1 + buffer1;
+    {   // distance_circles' pick (one_leg.cu:334) with res == resflip == false: the strictly shorter DIRECT candidate, else the flipped one
+        const bool take = twin && !(lrm_norm3(q) < lrm_norm3(q1));
+        q.x = take ? q1.x : q.x;
+        q.y = take ? q1.y : q.y;
+        q.z = take ? q1.z : q.z;
     }
     buffer = q.x * X.sin_pitch_rev;
     q.x = q.x * X.cos_pitch_rev - q.z * X.sin_pitch_rev;

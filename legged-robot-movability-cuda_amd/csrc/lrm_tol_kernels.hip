@@ -350,6 +350,12 @@ constexpr int kTabSegCap = LRM_TOL_TAB_SEG_CAP; // doubt slots per workgroup of 
 #ifndef LRM_SHORT_CAP
 #define LRM_SHORT_CAP 64 // LDS slots per wave for the short vectors of LRM_MODE_TOL_REL (~15 expected over a wave's five rounds; a segment without room for a round's records is replayed on the spot)
 #endif
+// The replayed vectors leave with non-temporal stores as well: ordinary ones make the L2 fetch the rest of each line (the tolerance
+// vectors of the neighbours, streamed out moments before) from memory: 92.97 -> 88.34 us per 1e7 points, 128.2 -> 108.1 us per 1.25e7
+// (profiles/r04_ab_rel_fixup.txt; the fix-up's few stores gain nothing from it: 14.2 -> 14.3 us, 14.6 -> 16.5 at 1.25e7)
+#ifndef LRM_REPLAY_NT_STORE
+#define LRM_REPLAY_NT_STORE 1
+#endif
 constexpr int kShortCap = LRM_SHORT_CAP;
 static_assert(kShortCap >= 64, "an emptied segment holds one round of a wave");
 __device__ __forceinline__ void wave_lds_fence_tol() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -415,14 +421,23 @@ __global__ __launch_bounds__(kBlock, kShort ? LRM_SHORT_MIN_WAVES : LRM_TAB_MIN_
             const size_t i = r[0];
             LrmVec3 q{lrm_u2f(r[1]), lrm_u2f(r[2]), lrm_u2f(r[3])};
             lrm_xtab_replay(lrm_fresh(X), s_tab.rows, q, r[4]);
+#if defined(LRM_EXP_NOSCATTER) // timing experiment (wrong results): the replayed vectors are computed but (practically) never stored
+            if (!(q.x != q.x)) return;
+#endif
             if (kAoS) {
                 dx[3 * i] = q.x;
                 dx[3 * i + 1] = q.y;
                 dx[3 * i + 2] = q.z;
             } else {
+#if LRM_REPLAY_NT_STORE
+                __builtin_nontemporal_store(q.x, dx + i);
+                __builtin_nontemporal_store(q.y, dy + i);
+                __builtin_nontemporal_store(q.z, dz + i);
+#else
                 dx[i] = q.x;
                 dy[i] = q.y;
                 dz[i] = q.z;
+#endif
             }
         }
     };
@@ -465,8 +480,12 @@ __global__ __launch_bounds__(kBlock, kShort ? LRM_SHORT_MIN_WAVES : LRM_TAB_MIN_
 #endif
         uint32_t doubt = 0;
         const LrmVec3 p_in = p; // kept for the queue record (three registers; re-loading it cost a pushing wave an L2 round trip)
-        uint32_t info = 0; // kShort: what the evaluation decided (the fix-up replays the winner's value chain from it)
+        uint32_t info = 0; // kShort: what the evaluation decided (the tail replays the winner's value chain from it)
+#if defined(LRM_EXP_NOINFO) // timing experiment (wrong results): the decisions are not packed
+        const bool m = lrm_tab_point<false>(L, G, p, doubt, &info) && live;
+#else
         const bool m = lrm_tab_point<kShort>(L, G, p, doubt, &info) && live;
+#endif
         doubt = live ? ((doubt & 0xffffu) | (selftest & 1u)) : 0u; // selftest: every point goes to the fix-up
         bool is_short = false;
         if (kShort) { // LRM_MODE_TOL_REL: a vector shorter than the threshold (and not in doubt) gets its value chain replayed strictly
@@ -539,7 +558,11 @@ __global__ __launch_bounds__(kBlock, kShort ? LRM_SHORT_MIN_WAVES : LRM_TAB_MIN_
     if (kShort && lane == 0) s_wcnt[wave_s] = wq;
     __syncthreads(); // (also orders this workgroup's stores of the tolerance vectors before the replayed ones below)
     if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
+#if defined(LRM_EXP_NOTAIL) // timing experiment (wrong results): the short vectors are recorded but never replayed
+    if (false) {
+#else
     if (kShort) {
+#endif
         // ---- the tail: what is left in the four segments, compacted over the workgroup's waves (usually its first wave alone) ----
         static_assert(kBlock / 64 == 4, "four wave segments");
         const uint32_t c0 = s_wcnt[0], c1 = c0 + s_wcnt[1], c2 = c1 + s_wcnt[2], total = c2 + s_wcnt[3];
