@@ -92,7 +92,7 @@ def test_tol_plane_table_vs_oracle(lrm, oracle, legname, az, q, shift):
     m2, d2, doubt2 = lrm.dbg_tol_host(pts, leg, q)
     both = sure & ((doubt2 & 0xffff) == 0)
     assert np.array_equal(m[both], m2[both])
-    assert (np.abs(d[both] - d2[both]) <= 1e-3 + 1e-6 * np.abs(d2[both])).all()  # (a few ulp of the vector where it is metres long)
+    assert (np.abs(d[both] - d2[both]) <= 1e-3 + 1e-6 * np.linalg.norm(d2[both], axis=1, keepdims=True)).all()  # (a few ulp of the vector's LENGTH in every component where it is metres long)
 
 
 @pytest.mark.parametrize("legname,az,q", [("m2", 0.0, QUATS[0]), ("moonbot", np.pi / 3, QUATS[1]), ("m2", -2.0, QUATS[3])])
