@@ -24,7 +24,7 @@ def main():
     mask = torch.empty(n, dtype=torch.uint8, device="cuda")
     field = torch.empty((3, n), dtype=torch.float32, device="cuda")
     bits = torch.empty((n + 63) // 64, dtype=torch.int64, device="cuda")
-    lrm_amd.set_mode(lrm_amd.MODE_TOL)
+    lrm_amd.set_mode(lrm_amd.MODE_TOL_REL if "--rel" in sys.argv else lrm_amd.MODE_TOL)  # --rel: the headline mode's launches
     for _ in range(300):  # steady clocks
         lrm_amd.device.reach_dist(cloud[0], cloud[1], cloud[2], leg, None, mask=mask, out=field, bits=bits)
     torch.cuda.synchronize()
