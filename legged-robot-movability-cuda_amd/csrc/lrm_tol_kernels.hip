@@ -356,6 +356,9 @@ constexpr int kTabSegCap = LRM_TOL_TAB_SEG_CAP; // doubt slots per workgroup of 
 #ifndef LRM_REPLAY_NT_STORE
 #define LRM_REPLAY_NT_STORE 1
 #endif
+#ifndef LRM_SHORT_TAIL_WAIT
+#define LRM_SHORT_TAIL_WAIT 1
+#endif
 constexpr int kShortCap = LRM_SHORT_CAP;
 static_assert(kShortCap >= 64, "an emptied segment holds one round of a wave");
 __device__ __forceinline__ void wave_lds_fence_tol() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -556,7 +559,13 @@ __global__ __launch_bounds__(kBlock, kShort ? LRM_SHORT_MIN_WAVES : LRM_TAB_MIN_
         }
     }
     if (kShort && lane == 0) s_wcnt[wave_s] = wq;
-    __syncthreads(); // (also orders this workgroup's stores of the tolerance vectors before the replayed ones below)
+#if LRM_SHORT_TAIL_WAIT
+    // The replayed vectors below overwrite tolerance vectors stored by OTHER waves of this workgroup: every wave first waits until
+    // its own stores have been acknowledged by the L2 (the workgroup-scope fence of __syncthreads does not: one CU, one L1 -- it
+    // relies on the CU's stores to one address reaching the L2 in issue order).
+    if (kShort) __builtin_amdgcn_s_waitcnt(0);
+#endif
+    __syncthreads();
     if (threadIdx.x == 0) counts[blockIdx.x] = s_qn;
 #if defined(LRM_EXP_NOTAIL) // timing experiment (wrong results): the short vectors are recorded but never replayed
     if (false) {
