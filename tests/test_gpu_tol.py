@@ -184,6 +184,34 @@ def test_tol_rel_mode_meets_the_literal_contract(lrm, oracle, torch_cuda, n, leg
     assert npts == n and nover == 0 and nq / npts < (0.03 if n >= 200_000 else 0.2)  # (below 2e5 points the staged kernel queues the short vectors for the fix-up)
 
 
+@pytest.mark.parametrize("n", [300_000, 1_000_003])
+def test_tol_rel_through_the_float3_boundary_and_the_distance_only_op(lrm, oracle, torch_cuda, n):
+    """LRM_MODE_TOL_REL behind the other entry points of the path: the host float3 arrays of the apply_kernel boundary
+    (lrm_dist / lrm_reach_dist: dist_tab_kernel<., true, true>) and the distance-only launch with validity bytes on device SoA
+    arrays -- the literal contract on every vector, flags bit for bit, short vectors bit-identical."""
+    pts = random_cloud(n, seed=91)
+    leg = lrm.get_M2_leg(-0.7)
+    q = (0.9239, 0.0, 0.0, 0.3827)
+    want_d, want_v = oracle.dist(pts, leg, q)
+    want_m = oracle.reach(pts, leg, q)
+    nref = np.linalg.norm(want_d.astype(np.float64), axis=1)
+    x, y, z = soa(torch_cuda, pts)
+    lrm.set_mode(lrm.MODE_TOL_REL)
+    try:
+        d_aos, v_aos, _ = lrm.apply_dist(pts, leg, q)
+        m_aos, d2_aos, _ = lrm.apply_reach_dist(pts, leg, q)
+        d_dev, v_dev = lrm.device.dist(x, y, z, leg, q)
+        torch_cuda.cuda.synchronize()
+    finally:
+        lrm.set_mode(lrm.MODE_TOL)
+    for name, d, flags, want_flags in (("lrm_dist (float3)", d_aos, v_aos, want_v), ("lrm_reach_dist (float3)", d2_aos, m_aos, want_m),
+                                       ("lrm_dist_dev (SoA)", d_dev.cpu().numpy().T, v_dev.cpu().numpy(), want_v)):
+        assert np.array_equal(np.asarray(flags).astype(bool), np.asarray(want_flags).astype(bool)), name
+        err = np.linalg.norm(np.asarray(d, np.float64) - want_d.astype(np.float64), axis=1)
+        assert (err <= TOL * nref).all(), (name, float((err / np.maximum(nref, 1e-300)).max()))
+        assert bits_equal(np.asarray(d, np.float32)[nref < 16.0], want_d[nref < 16.0]).all(), name
+
+
 def test_tol_rel_full_size_config2_1e7_points_against_the_oracle(lrm, oracle, torch_cuda):
     """The bench headline (LRM_MODE_TOL_REL on BASELINE config 2 at full size) against the ORACLE on all 1e7 points: reach mask
     and ballot words bit-identical, |d - d_ref| <= 1e-5 |d_ref| for EVERY vector (0 for a zero reference vector), every vector
