@@ -36,6 +36,7 @@
 #include <vector>
 #include "../../include/lrm.h"
 #include "lrm_compile.h"
+#include "lrm_launch.h"
 #include "lrm_point.h"
 #include "lrm_point_fast.h"
 #include "lrm_point_tol.h"
@@ -43,6 +44,9 @@
 namespace {
 
 constexpr int kOctBlock = 256;
+#ifndef LRM_OCT_MIN_WAVES
+#define LRM_OCT_MIN_WAVES 4 // 128 VGPRs (8 B/lane of scratch in the table form) instead of 153 at 3 waves: config-5 share 114 -> 100 ms; 5 waves (112 B of scratch): 116
+#endif
 
 struct OctChild {          // one child box of the level being evaluated
     float c[3], h[3];      // centre, half size ("topOffset")
@@ -75,9 +79,11 @@ __device__ __forceinline__ bool in_box(LrmVec3 v, float hx, float hy, float hz) 
 // contract-tolerance evaluation (lrm_dist_tol, lrm_point_tol.h: ~500 instructions instead of the filtered code's ~1000) answers
 // them unless one of its own decisions is in doubt or the vector ends within its error of a face of the box (of the sphere);
 // those few evaluations are redone by the filtered code.  Same flags either way (tests/test_gpu_octree.py).
-template <bool kFast>
+// kTol: 0 the filtered code alone, 1 the tolerance evaluation without a table first, 2 through the plane tables (one instantiation
+// each: with both tolerance forms inlined the kernel lost a fifth of its speed to registers)
+template <bool kFast, int kTol>
 __device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 vect, float h2, float hd, const LrmCompiledLeg* __restrict__ legs,
-                                                   const LrmTolLeg* __restrict__ tols,
+                                                   const LrmTolLeg* __restrict__ tols, const uint8_t* const* __restrict__ tabs,
                                                    const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float convex_r2) {
     uint32_t mine = 0;
     for (int a = 0; a < ch.n_angles; a++) {
@@ -100,12 +106,26 @@ __device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 v
             const LrmCompiledLeg& L = legs[a * leg_count + l];
             LrmVec3 v = vect;
             bool sub = false, done = false;
-            if (kFast && tols) {
+            if (kFast && kTol != 0) {
                 const LrmTolLeg& TL = tols[a * leg_count + l];
                 if (TL.tol_ok) { // (wave-uniform)
                     uint32_t dbt = 0;
                     LrmVec3 tv = vect;
-                    const bool tsub = lrm_dist_tol(TL, LrmTolTables{&TL.circ[0][0], &TL.feat[0]}, tv, dbt);
+                    // (orientation, leg) is the same for the whole wave: the table's header, rows and bounds are read through a uniform base
+                    // straight from global memory (L2-resident: a level walks 4 x 27 tables at most)
+                    const uint8_t* tab = kTol == 2 ? tabs[a * leg_count + l] : nullptr;
+                    bool tsub = false;
+                    if (kTol == 2) {
+                        if (!tab) dbt = 1u; // (a leg without a table: the filtered code below)
+                        else {
+                        const LrmTolTabHeader* hd = reinterpret_cast<const LrmTolTabHeader*>(tab);
+                        const LrmTolTabView G = lrm_toltab_view(tab, hd->rows, hd->vrows,
+                                                                reinterpret_cast<const uint32_t*>(tab + sizeof(LrmTolTabHeader) + 2 * (size_t)hd->bound_off[0]), TL.r_outer);
+                        tsub = lrm_tab_point(TL, G, tv, dbt);
+                        }
+                    } else {
+                        tsub = lrm_dist_tol(TL, LrmTolTables{&TL.circ[0][0], &TL.feat[0]}, tv, dbt);
+                    }
                     // the tolerance vector is within 1e-5 of max(|d|, (|p| + body) / 8) of the reference's (include/lrm.h): eps covers it twice
                     const float eps = 2.0e-5f * (fabsf(tv.x) + fabsf(tv.y) + fabsf(tv.z) + fabsf(vect.x) + fabsf(vect.y) + fabsf(vect.z) + 400.f) + 1.0e-3f;
                     bool near_face;
@@ -139,11 +159,12 @@ __device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 v
     return mine;
 }
 
-template <bool kFast>
-__global__ __launch_bounds__(kOctBlock) void oct_validity_kernel(
+template <bool kFast, int kTol>
+__global__ __launch_bounds__(kOctBlock, LRM_OCT_MIN_WAVES) void oct_validity_kernel(
     const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
     const float* __restrict__ fy, const float* __restrict__ fz, size_t nf,
     const LrmCompiledLeg* __restrict__ legs /* [n_angles_max][leg_count] */, const LrmTolLeg* __restrict__ tols /* same shape, or null */,
+    const uint8_t* const* __restrict__ tabs /* the plane tables (lrm_toltab_build.h) of the same (orientation, leg) pairs, or null */,
     const float4* __restrict__ spheres /* same shape */, int leg_count, int legs_for_stab,
     float reach_len, float convex_r2, uint32_t* __restrict__ flags /* per child: 1 reach, 2 valid leaf, 4 edge */) {
     const OctChild ch = children[blockIdx.y];
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_kernel(
         const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
         // elongated parent box, several_leg_octree.cu:76-82
         if (!in_box(vect, ch.ph[0] + reach_len, ch.ph[1] + reach_len, ch.ph[2] + reach_len)) continue;
-        mine |= oct_item_flags<kFast>(ch, vect, h2, hd, legs, tols, spheres, leg_count, legs_for_stab, convex_r2);
+        mine |= oct_item_flags<kFast, kTol>(ch, vect, h2, hd, legs, tols, tabs, spheres, leg_count, legs_for_stab, convex_r2);
     }
     // wave OR, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) mine |= __shfl_xor(mine, off);
@@ -228,11 +249,11 @@ __device__ __forceinline__ bool box_meets(const float* bb, const float* c, const
            bb[2] <= c[2] + H[2] && bb[5] >= c[2] - H[2];
 }
 
-template <bool kFast>
-__global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
+template <bool kFast, int kTol>
+__global__ __launch_bounds__(kOctBlock, LRM_OCT_MIN_WAVES) void oct_validity_chunked_kernel(
     const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
     const float* __restrict__ fy, const float* __restrict__ fz, size_t nf, const float* __restrict__ boxes, size_t ntiles,
-    const LrmCompiledLeg* __restrict__ legs, const LrmTolLeg* __restrict__ tols, const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float reach_len,
+    const LrmCompiledLeg* __restrict__ legs, const LrmTolLeg* __restrict__ tols, const uint8_t* const* __restrict__ tabs, const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float reach_len,
     float convex_r2, uint32_t* __restrict__ flags /* zeroed by the host */, uint32_t splits) {
     __shared__ uint32_t s_flags, s_ntiles, s_nchunks;
     __shared__ uint32_t s_tiles[kOctBlock];
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(kOctBlock) void oct_validity_chunked_kernel(
                 if (f < nf) {
                     const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
                     if (in_box(vect, ch.ph[0] + reach_len, ch.ph[1] + reach_len, ch.ph[2] + reach_len)) {
-                        mine = oct_item_flags<kFast>(ch, vect, h2, hd, legs, tols, spheres, leg_count, legs_for_stab, convex_r2);
+                        mine = oct_item_flags<kFast, kTol>(ch, vect, h2, hd, legs, tols, tabs, spheres, leg_count, legs_for_stab, convex_r2);
                     }
                 }
                 for (int off = 32; off > 0; off >>= 1) mine |= __shfl_xor(mine, off);
@@ -541,6 +562,7 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
     void* d_sort_tmp = nullptr;
     float4* d_spheres = nullptr;
     LrmTolLeg* d_tols = nullptr;
+    const uint8_t** d_tabs = nullptr; // device array of the plane tables' device pointers (the tables themselves live in the cache below)
     LrmCompiledLeg* d_legs = nullptr;
     OctChild* d_children = nullptr;
     uint32_t* d_flags = nullptr;
@@ -556,6 +578,7 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
         if (d_legs) (void)hipFree(d_legs);
         if (d_spheres) (void)hipFree(d_spheres);
         if (d_tols) (void)hipFree(d_tols);
+        if (d_tabs) (void)hipFree(d_tabs);
         if (d_children) (void)hipFree(d_children);
         if (d_flags) (void)hipFree(d_flags);
         if (ev_a) (void)hipEventDestroy(ev_a);
@@ -645,8 +668,19 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
         const bool want = fast && (e ? e[0] != '0' : nf >= 300000);
         if (want) {
             static std::mutex mu;
-            static std::map<std::array<float, 18>, LrmTolLeg> cache;
+            struct Entry {
+                LrmTolLeg tl;
+                std::map<int, uint8_t*> tab_dev; // per device: the plane table (lrm_build_tol_tab_dev), nullptr = this leg has none
+            };
+            static std::map<std::array<float, 18>, Entry> cache;
             std::vector<LrmTolLeg> tols(legs.size());
+            std::vector<const uint8_t*> tabs(legs.size(), nullptr);
+            // the plane tables (LRM_OCT_TAB=0: without): built on the device on first use, ~0.4 ms each, kept across calls
+            const char* et = getenv("LRM_OCT_TAB");
+            const bool want_tab = et ? et[0] != '0' : true;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            bool any_tab = false;
             std::lock_guard<std::mutex> g(mu);
             for (int a = 0; a < n_angles_max; a++) {
                 const Quat q = quat_from_angle_index((unsigned)a, st);
@@ -658,16 +692,38 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
                     key[14] = q.x; key[15] = q.y; key[16] = q.z; key[17] = q.w;
                     auto it = cache.find(key);
                     if (it == cache.end()) {
-                        if (cache.size() >= 1024) cache.clear();
-                        LrmTolLeg tl;
-                        lrm_compile_tol(legs[(size_t)a * st.leg_count + l], &tl);
-                        it = cache.emplace(key, tl).first;
+                        if (cache.size() >= 1024) {
+                            for (auto& kv : cache)
+                                for (auto& dt : kv.second.tab_dev)
+                                    if (dt.second) (void)hipFree(dt.second); // (no launch of an earlier call is still running: every call ends with a synchronous copy)
+                            cache.clear();
+                        }
+                        Entry en;
+                        lrm_compile_tol(legs[(size_t)a * st.leg_count + l], &en.tl);
+                        it = cache.emplace(key, en).first;
                     }
-                    tols[(size_t)a * st.leg_count + l] = it->second;
+                    tols[(size_t)a * st.leg_count + l] = it->second.tl;
+                    if (want_tab && it->second.tl.tol_ok) {
+                        auto dt = it->second.tab_dev.find(dev);
+                        if (dt == it->second.tab_dev.end()) {
+                            uint8_t* t = nullptr;
+                            size_t bytes = 0;
+                            float ms = 0.f;
+                            const int rc = lrm_build_tol_tab_dev(it->second.tl, nullptr, &t, &bytes, &ms);
+                            if (rc < 0) OCT_TRY((hipError_t)(-rc), "plane table (device builder)");
+                            dt = it->second.tab_dev.emplace(dev, rc == 0 ? t : nullptr).first;
+                        }
+                        tabs[(size_t)a * st.leg_count + l] = dt->second;
+                        any_tab = any_tab || dt->second != nullptr;
+                    }
                 }
             }
             OCT_TRY(hipMalloc(&d_tols, tols.size() * sizeof(LrmTolLeg)), "hipMalloc tolerance blocks");
             OCT_TRY(hipMemcpy(d_tols, tols.data(), tols.size() * sizeof(LrmTolLeg), hipMemcpyHostToDevice), "hipMemcpy tolerance blocks");
+            if (any_tab) {
+                OCT_TRY(hipMalloc(reinterpret_cast<void**>(&d_tabs), tabs.size() * sizeof(uint8_t*)), "hipMalloc table pointers");
+                OCT_TRY(hipMemcpy(d_tabs, tabs.data(), tabs.size() * sizeof(uint8_t*), hipMemcpyHostToDevice), "hipMemcpy table pointers");
+            }
         }
     }
     OCT_TRY(hipMalloc(&d_legs, legs.size() * sizeof(LrmCompiledLeg)), "hipMalloc legs");
@@ -779,23 +835,25 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
                 splits = std::min(splits, std::max<size_t>(1, (ntiles + kOctBlock - 1) / kOctBlock));
                 splits = std::min<size_t>(splits, 64);
                 const dim3 grid((unsigned)std::min<size_t>(nc * splits, (size_t)256 * 64));
-                if (fast)
-                    hipLaunchKernelGGL(oct_validity_chunked_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits);
-                else
-                    hipLaunchKernelGGL(oct_validity_chunked_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits);
+#define LRM_OCT_CHUNKED(FAST, TOL) hipLaunchKernelGGL((oct_validity_chunked_kernel<FAST, TOL>), grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf, \
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_tabs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits)
+                if (fast && d_tabs) LRM_OCT_CHUNKED(true, 2);
+                else if (fast && d_tols) LRM_OCT_CHUNKED(true, 1);
+                else if (fast) LRM_OCT_CHUNKED(true, 0);
+                else LRM_OCT_CHUNKED(false, 0);
+#undef LRM_OCT_CHUNKED
             } else {
                 // few, huge children (the first levels): every foothold, spread over the chip; grid.y = children < 65
                 size_t gx = (nf + kOctBlock - 1) / kOctBlock;
                 if (gx > 1024) gx = 1024;
                 const dim3 grid((unsigned)gx, (unsigned)nc);
-                if (fast)
-                    hipLaunchKernelGGL(oct_validity_kernel<true>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_legs, d_tols, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
-                else
-                    hipLaunchKernelGGL(oct_validity_kernel<false>, grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_legs, d_tols, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags);
+#define LRM_OCT_EVERY(FAST, TOL) hipLaunchKernelGGL((oct_validity_kernel<FAST, TOL>), grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf, \
+                                       d_f + 2 * nf, nf, d_legs, d_tols, d_tabs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags)
+                if (fast && d_tabs) LRM_OCT_EVERY(true, 2);
+                else if (fast && d_tols) LRM_OCT_EVERY(true, 1);
+                else if (fast) LRM_OCT_EVERY(true, 0);
+                else LRM_OCT_EVERY(false, 0);
+#undef LRM_OCT_EVERY
             }
             OCT_TRY(hipGetLastError(), "Kernel launch");
             OCT_TRY(hipEventRecord(ev_b, nullptr), "hipEventRecord");

@@ -8,13 +8,15 @@ from octree_oracle import apply_oct as oracle_apply_oct
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["strict", "fast", "fast_tol"])
+@pytest.fixture(autouse=True, params=["strict", "fast", "fast_tol", "fast_tab"])
 def mode(request, lrm, monkeypatch):
     """strict: lrm_point.h verbatim; fast: the filtered code for every work item (LRM_OCT_TOL=0); fast_tol: the contract-tolerance
     evaluation first, the filtered code for its doubts and for vectors that end near a face of the child box (LRM_OCT_TOL=1: whatever
-    the cloud's size; the library's default takes it from 3e5 footholds on).  All three must give the same leaves."""
+    the cloud's size; the library's default takes it from 3e5 footholds on), without plane tables (LRM_OCT_TAB=0); fast_tab: the same
+    through the plane tables of the (orientation, leg) pairs (the default).  All four must give the same leaves."""
     lrm.set_mode(lrm.MODE_STRICT if request.param == "strict" else lrm.MODE_FAST)
-    monkeypatch.setenv("LRM_OCT_TOL", "1" if request.param == "fast_tol" else "0")
+    monkeypatch.setenv("LRM_OCT_TOL", "1" if request.param in ("fast_tol", "fast_tab") else "0")
+    monkeypatch.setenv("LRM_OCT_TAB", "1" if request.param == "fast_tab" else "0")
     yield request.param
     lrm.set_mode(lrm.MODE_FAST)
 
