@@ -84,9 +84,11 @@ __device__ __forceinline__ bool in_box(LrmVec3 v, float hx, float hy, float hz) 
 template <bool kFast, int kTol>
 __device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 vect, float h2, float hd, const LrmCompiledLeg* __restrict__ legs,
                                                    const LrmTolLeg* __restrict__ tols, const uint8_t* const* __restrict__ tabs,
-                                                   const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float convex_r2) {
+                                                   const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float convex_r2,
+                                                   int a_begin = 0, int a_end = -1 /* orientations [a_begin, a_end); -1: all of the child's */) {
     uint32_t mine = 0;
-    for (int a = 0; a < ch.n_angles; a++) {
+    if (a_end < 0) a_end = ch.n_angles;
+    for (int a = a_begin; a < a_end; a++) {
         int near = 0;
         uint32_t near_bits = 0;
         for (int l = 0; l < leg_count; l++) {
@@ -155,6 +157,148 @@ __device__ __forceinline__ uint32_t oct_item_flags(const OctChild& ch, LrmVec3 v
         const bool edge = cross_count > leg_count - legs_for_stab;
         const bool reach = ch.parent_valid || (reach_count >= legs_for_stab);
         mine |= (reach ? 1u : 0u) | ((reach && !edge) ? 2u : 0u) | (edge ? 4u : 0u);
+    }
+    return mine;
+}
+
+// ---- the table form with its doubts DEFERRED (round 4) -------------------------------------------------------------------
+// Inlined next to the table evaluation, the filtered code of the doubtful evaluations (a few per cent) sets the kernel's register
+// count (153 VGPRs, 3-4 waves per SIMD).  Here an (item, orientation) with a doubtful leg contributes nothing in the main
+// kernel: a record {child, foothold, orientation} goes to the wave's LDS segment (count in a scalar register, no atomic), full
+// segments to a global queue (one atomic per flush), and oct_deferred_kernel evaluates the queued (item, orientation) pairs
+// with the filtered code for every leg and ORs their flags in.  The flags are ORs: the order changes nothing; a queue that
+// overflows raises a flag and the host runs the level again with the inline form.
+struct OctDeferQueue {
+    uint32_t* rec;   // three words per record
+    uint32_t* count; // [0] records, [1] overflowed
+    uint32_t cap;
+};
+// records of the global queue: 2-3 % of a level's evaluated (item, orientation) pairs are deferred -- 6.9e6 at the deepest level of the
+// config-5 share (1.25e7 footholds): one record per foothold, within [2^20, 2^25] (12 bytes each)
+static size_t oct_defer_cap(size_t nf) {
+    if (const char* e = getenv("LRM_OCT_DEFER_CAP")) return std::max<size_t>((size_t)atol(e), 64); // tests: a queue that overflows
+    return std::min<size_t>(std::max<size_t>(nf, (size_t)1 << 20), (size_t)1 << 25);
+}
+constexpr int kOctDeferSeg = 64; // records per wave segment: one ballot's worth always fits an emptied segment
+
+__device__ __forceinline__ void oct_wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// all 64 lanes together
+__device__ __forceinline__ void oct_defer_flush(uint32_t* seg, uint32_t& wq, const OctDeferQueue Q) {
+    if (wq == 0u) return; // wave-uniform
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0u) base = atomicAdd(Q.count, wq);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base + wq <= Q.cap) {
+        if (lane < wq) {
+            Q.rec[3u * (base + lane)] = seg[3u * lane];
+            Q.rec[3u * (base + lane) + 1u] = seg[3u * lane + 1u];
+            Q.rec[3u * (base + lane) + 2u] = seg[3u * lane + 2u];
+        }
+    } else if (lane == 0u) {
+        atomicOr(Q.count + 1, 1u);
+    }
+    oct_wave_fence();
+    wq = 0u;
+}
+// oct_item_flags<true, 2> for a whole wave (every lane calls it; `act`: this lane has an item), doubts deferred
+__device__ __forceinline__ uint32_t oct_item_flags_defer(const OctChild& ch, bool act, LrmVec3 vect, float h2, float hd,
+                                                         const LrmTolLeg* __restrict__ tols, const uint8_t* const* __restrict__ tabs,
+                                                         const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float convex_r2,
+                                                         uint32_t* seg, uint32_t& wq, uint32_t child, uint32_t f, const OctDeferQueue Q) {
+    uint32_t mine = 0;
+    for (int a = 0; a < ch.n_angles; a++) {
+        int near = 0;
+        uint32_t near_bits = 0;
+        for (int l = 0; l < leg_count; l++) {
+            const float4 sp = spheres[a * leg_count + l];
+            const float ex = vect.x - sp.x, ey = vect.y - sp.y, ez = vect.z - sp.z, rr = sp.w + hd;
+            const bool in = ex * ex + ey * ey + ez * ez < rr * rr;
+            near += in ? 1 : 0;
+            near_bits |= in ? (1u << l) : 0u;
+        }
+        const bool culled = near < legs_for_stab && near <= leg_count - legs_for_stab;
+        if (act && culled) mine |= ch.parent_valid ? 3u : 0u;
+        const bool eval = act && !culled;
+        bool dfr = false;
+#if defined(LRM_OCT_COUNT)
+        uint32_t why = 0;
+#endif
+        int reach_count = 0, cross_count = 0;
+        if (__ballot(eval) != 0ull) {
+            for (int l = 0; l < leg_count; l++) {
+                const bool on = eval && !dfr && ((near_bits >> l) & 1u) != 0u;
+                if (__ballot(on) == 0ull) continue; // wave-uniform
+                const LrmTolLeg& TL = tols[a * leg_count + l];
+                const uint8_t* tab = tabs[a * leg_count + l];
+                if (!TL.tol_ok || !tab) { // (wave-uniform) a leg without a table: its items go to the filtered code
+                    dfr = dfr || on;
+#if defined(LRM_OCT_COUNT)
+                    if (on) why = 1u;
+#endif
+                    continue;
+                }
+                if (on) {
+                    uint32_t dbt = 0;
+                    LrmVec3 tv = vect;
+                    const LrmTolTabHeader* hd_ = reinterpret_cast<const LrmTolTabHeader*>(tab);
+                    const LrmTolTabView G = lrm_toltab_view(tab, hd_->rows, hd_->vrows,
+                                                            reinterpret_cast<const uint32_t*>(tab + sizeof(LrmTolTabHeader) + 2 * (size_t)hd_->bound_off[0]), TL.r_outer);
+                    const bool tsub = lrm_tab_point(TL, G, tv, dbt);
+                    const float eps = 2.0e-5f * (fabsf(tv.x) + fabsf(tv.y) + fabsf(tv.z) + fabsf(vect.x) + fabsf(vect.y) + fabsf(vect.z) + 400.f) + 1.0e-3f; // as oct_item_flags
+                    bool near_face, cross;
+                    if (h2 > convex_r2) {
+                        near_face = fabsf(fabsf(tv.x) - fabsf(ch.h[0])) < eps || fabsf(fabsf(tv.y) - fabsf(ch.h[1])) < eps || fabsf(fabsf(tv.z) - fabsf(ch.h[2])) < eps;
+                        cross = in_box(tv, ch.h[0], ch.h[1], ch.h[2]);
+                    } else {
+                        const float n2 = tv.x * tv.x + tv.y * tv.y + tv.z * tv.z;
+                        near_face = fabsf(sqrtf(n2) - sqrtf(fmaxf(h2 + ch.margin, 0.f))) < eps;
+                        cross = n2 < h2 + ch.margin;
+                    }
+#if defined(LRM_OCT_COUNT)
+                    if ((dbt & 0xffffu) != 0u) why = 2u; else if (near_face) why = 3u;
+                    if ((dbt & 0xffffu) != 0u && (threadIdx.x & 63u) < 64u) atomicAdd(Q.count + 8 + (31 - __builtin_clz(dbt & 0xffffu)), 1u);
+#endif
+                    if ((dbt & 0xffffu) != 0u || near_face) dfr = true;
+                    else {
+                        cross_count += cross;
+                        reach_count += tsub;
+                    }
+                }
+            }
+        }
+        if (eval && !dfr) {
+            const bool edge = cross_count > leg_count - legs_for_stab;
+            const bool reach = ch.parent_valid || (reach_count >= legs_for_stab);
+            mine |= (reach ? 1u : 0u) | ((reach && !edge) ? 2u : 0u) | (edge ? 4u : 0u);
+        }
+#if defined(LRM_OCT_COUNT) // counting build: evaluated (item, orientation) pairs in count[2], deferred for a missing table / a doubt bit / a near face in [3..5]
+        {
+            const unsigned long long em = __ballot(eval);
+            if ((threadIdx.x & 63u) == 0u && em) atomicAdd(Q.count + 2, (uint32_t)__builtin_popcountll(em));
+            const unsigned long long c3 = __ballot(dfr && why == 1u), c4 = __ballot(dfr && why == 2u), c5 = __ballot(dfr && why == 3u);
+            if ((threadIdx.x & 63u) == 0u && c3) atomicAdd(Q.count + 3, (uint32_t)__builtin_popcountll(c3));
+            if ((threadIdx.x & 63u) == 0u && c4) atomicAdd(Q.count + 4, (uint32_t)__builtin_popcountll(c4));
+            if ((threadIdx.x & 63u) == 0u && c5) atomicAdd(Q.count + 5, (uint32_t)__builtin_popcountll(c5));
+        }
+#endif
+        const unsigned long long dm = __ballot(dfr);
+        if (dm != 0ull) { // wave-uniform
+            const uint32_t n = (uint32_t)__builtin_popcountll(dm);
+            if (wq + n > (uint32_t)kOctDeferSeg) oct_defer_flush(seg, wq, Q);
+            const uint32_t pos = wq + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+            if (dfr) {
+                seg[3u * pos] = child;
+                seg[3u * pos + 1u] = f;
+                seg[3u * pos + 2u] = (uint32_t)a;
+            }
+            wq += n;
+            oct_wave_fence();
+        }
     }
     return mine;
 }
@@ -249,13 +393,20 @@ __device__ __forceinline__ bool box_meets(const float* bb, const float* c, const
            bb[2] <= c[2] + H[2] && bb[5] >= c[2] - H[2];
 }
 
-template <bool kFast, int kTol>
-__global__ __launch_bounds__(kOctBlock, LRM_OCT_MIN_WAVES) void oct_validity_chunked_kernel(
+#ifndef LRM_OCT_DEFER_MIN_WAVES
+#define LRM_OCT_DEFER_MIN_WAVES 5
+#endif
+template <bool kFast, int kTol, bool kDefer = false>
+__global__ __launch_bounds__(kOctBlock, kDefer ? LRM_OCT_DEFER_MIN_WAVES : LRM_OCT_MIN_WAVES) void oct_validity_chunked_kernel(
     const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
     const float* __restrict__ fy, const float* __restrict__ fz, size_t nf, const float* __restrict__ boxes, size_t ntiles,
     const LrmCompiledLeg* __restrict__ legs, const LrmTolLeg* __restrict__ tols, const uint8_t* const* __restrict__ tabs, const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float reach_len,
-    float convex_r2, uint32_t* __restrict__ flags /* zeroed by the host */, uint32_t splits) {
+    float convex_r2, uint32_t* __restrict__ flags /* zeroed by the host */, uint32_t splits, const OctDeferQueue Q /* kDefer */) {
+    static_assert(!kDefer || (kFast && kTol == 2), "the deferred form is the table form");
     __shared__ uint32_t s_flags, s_ntiles, s_nchunks;
+    __shared__ uint32_t s_defer[kDefer ? (kOctBlock / 64) * kOctDeferSeg * 3 : 1];
+    uint32_t* dseg = s_defer + (kDefer ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (uint32_t)(kOctDeferSeg * 3) : 0u);
+    uint32_t dwq = 0; // kDefer: records waiting in this wave's segment (wave-uniform)
     __shared__ uint32_t s_tiles[kOctBlock];
     __shared__ uint32_t s_chunks[kOctMaxChunks];
     // A level with few, large children would leave most of the chip idle at one workgroup per child: `splits` workgroups
@@ -298,7 +449,13 @@ __global__ __launch_bounds__(kOctBlock, LRM_OCT_MIN_WAVES) void oct_validity_chu
                 if (*reinterpret_cast<volatile uint32_t*>(&s_flags) == 7u) break;
                 const size_t f = (size_t)s_chunks[k] * 64 + (threadIdx.x & 63);
                 uint32_t mine = 0;
-                if (f < nf) {
+                if (kDefer) { // every lane of the wave together (ballots inside)
+                    const bool live = f < nf;
+                    const size_t fl = live ? f : 0;
+                    const LrmVec3 vect{fx[fl] - ch.c[0], fy[fl] - ch.c[1], fz[fl] - ch.c[2]};
+                    const bool act = live && in_box(vect, ch.ph[0] + reach_len, ch.ph[1] + reach_len, ch.ph[2] + reach_len);
+                    mine = oct_item_flags_defer(ch, act, vect, h2, hd, tols, tabs, spheres, leg_count, legs_for_stab, convex_r2, dseg, dwq, (uint32_t)child, (uint32_t)f, Q);
+                } else if (f < nf) {
                     const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
                     if (in_box(vect, ch.ph[0] + reach_len, ch.ph[1] + reach_len, ch.ph[2] + reach_len)) {
                         mine = oct_item_flags<kFast, kTol>(ch, vect, h2, hd, legs, tols, tabs, spheres, leg_count, legs_for_stab, convex_r2);
@@ -312,6 +469,26 @@ __global__ __launch_bounds__(kOctBlock, LRM_OCT_MIN_WAVES) void oct_validity_chu
         __syncthreads();
         if (threadIdx.x == 0 && s_flags) atomicOr(&flags[child], s_flags);
         __syncthreads();
+    }
+    if (kDefer) oct_defer_flush(dseg, dwq, Q);
+}
+
+// The queued (item, orientation) pairs of oct_validity_chunked_kernel<true, 2, true>: every leg by the filtered code.
+__global__ __launch_bounds__(kOctBlock) void oct_deferred_kernel( // (every lane its own child and orientation: 150 VGPRs; a few per cent of the work)
+    const OctChild* __restrict__ children, const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ fz,
+    const LrmCompiledLeg* __restrict__ legs, const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float convex_r2,
+    uint32_t* __restrict__ flags, const OctDeferQueue Q) {
+    const uint32_t n = Q.count[0] < Q.cap ? Q.count[0] : Q.cap;
+    for (uint32_t k = blockIdx.x * kOctBlock + threadIdx.x; k < n; k += gridDim.x * kOctBlock) {
+        const uint32_t child = Q.rec[3u * k], f = Q.rec[3u * k + 1u];
+        const int a = (int)Q.rec[3u * k + 2u];
+        if (*reinterpret_cast<volatile uint32_t*>(&flags[child]) == 7u) continue;
+        const OctChild ch = children[child];
+        const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
+        const float h2 = ch.h[0] * ch.h[0] + ch.h[1] * ch.h[1] + ch.h[2] * ch.h[2];
+        const float hd = sqrtf(h2 + fmaxf(ch.margin, 0.f)) * 1.0001f + 0.01f;
+        const uint32_t bits = oct_item_flags<true, 0>(ch, vect, h2, hd, legs, nullptr, nullptr, spheres, leg_count, legs_for_stab, convex_r2, a, a + 1);
+        if (bits) atomicOr(&flags[child], bits);
     }
 }
 
@@ -563,6 +740,8 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
     float4* d_spheres = nullptr;
     LrmTolLeg* d_tols = nullptr;
     const uint8_t** d_tabs = nullptr; // device array of the plane tables' device pointers (the tables themselves live in the cache below)
+    uint32_t *d_defer = nullptr, *d_defer_count = nullptr; // the queue of deferred (item, orientation) pairs (oct_item_flags_defer)
+    unsigned long long deferred_total = 0;
     LrmCompiledLeg* d_legs = nullptr;
     OctChild* d_children = nullptr;
     uint32_t* d_flags = nullptr;
@@ -579,6 +758,8 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
         if (d_spheres) (void)hipFree(d_spheres);
         if (d_tols) (void)hipFree(d_tols);
         if (d_tabs) (void)hipFree(d_tabs);
+        if (d_defer) (void)hipFree(d_defer);
+        if (d_defer_count) (void)hipFree(d_defer_count);
         if (d_children) (void)hipFree(d_children);
         if (d_flags) (void)hipFree(d_flags);
         if (ev_a) (void)hipEventDestroy(ev_a);
@@ -723,6 +904,11 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
             if (any_tab) {
                 OCT_TRY(hipMalloc(reinterpret_cast<void**>(&d_tabs), tabs.size() * sizeof(uint8_t*)), "hipMalloc table pointers");
                 OCT_TRY(hipMemcpy(d_tabs, tabs.data(), tabs.size() * sizeof(uint8_t*), hipMemcpyHostToDevice), "hipMemcpy table pointers");
+                const char* ed = getenv("LRM_OCT_DEFER"); // LRM_OCT_DEFER=0: the doubts of the table form inline (A/B runs and tests)
+                if (!ed || ed[0] != '0') {
+                    OCT_TRY(hipMalloc(reinterpret_cast<void**>(&d_defer), oct_defer_cap(nf) * 3 * sizeof(uint32_t)), "hipMalloc deferred pairs");
+                    OCT_TRY(hipMalloc(reinterpret_cast<void**>(&d_defer_count), 32 * sizeof(uint32_t)), "hipMalloc deferred count");
+                }
             }
         }
     }
@@ -836,8 +1022,33 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
                 splits = std::min<size_t>(splits, 64);
                 const dim3 grid((unsigned)std::min<size_t>(nc * splits, (size_t)256 * 64));
 #define LRM_OCT_CHUNKED(FAST, TOL) hipLaunchKernelGGL((oct_validity_chunked_kernel<FAST, TOL>), grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf, \
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_tabs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits)
-                if (fast && d_tabs) LRM_OCT_CHUNKED(true, 2);
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_tabs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits, OctDeferQueue{nullptr, nullptr, 0u})
+                bool deferred_done = false;
+                // the table form with its doubts queued for a second launch (see oct_item_flags_defer) -- from 256 children on: the few huge
+                // children of the first levels saturate their flags early, and later when some of their items wait in the queue
+                const size_t defer_from = getenv("LRM_OCT_DEFER_FROM") ? (size_t)atol(getenv("LRM_OCT_DEFER_FROM")) : (size_t)256;
+                if (fast && d_tabs && d_defer && nc >= defer_from) {
+                    const OctDeferQueue Q{d_defer, d_defer_count, (uint32_t)oct_defer_cap(nf)};
+                    OCT_TRY(hipMemsetAsync(d_defer_count, 0, 32 * sizeof(uint32_t), nullptr), "hipMemsetAsync");
+                    hipLaunchKernelGGL((oct_validity_chunked_kernel<true, 2, true>), grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_tabs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits, Q);
+                    OCT_TRY(hipGetLastError(), "Kernel launch");
+                    hipLaunchKernelGGL(oct_deferred_kernel, dim3(2048), dim3(kOctBlock), 0, nullptr, d_children, d_f, d_f + nf, d_f + 2 * nf, d_legs, d_spheres,
+                                       st.leg_count, st.leg_number_for_stab, cr2, d_flags, Q);
+                    OCT_TRY(hipGetLastError(), "Kernel launch");
+                    uint32_t qc[32] = {0};
+                    OCT_TRY(hipMemcpy(qc, d_defer_count, sizeof qc, hipMemcpyDeviceToHost), "hipMemcpy queue count");
+#if defined(LRM_OCT_COUNT)
+                    fprintf(stderr, "apply_oct: level %d: %u pairs evaluated, %u queued (overflow %u): no table %u, doubt %u, near face %u; doubt bits:", depth, qc[2], qc[0], qc[1], qc[3], qc[4], qc[5]);
+                    for (int b = 0; b < 16; b++) fprintf(stderr, " %u", qc[8 + b]);
+                    fprintf(stderr, "\n");
+#endif
+                    deferred_total += qc[0];
+                    if (qc[1] == 0) deferred_done = true;
+                    else OCT_TRY(hipMemset(d_flags, 0, nc * sizeof(uint32_t)), "hipMemset flags"); // the queue overflowed: the level again, doubts inline
+                }
+                if (deferred_done) {}
+                else if (fast && d_tabs) LRM_OCT_CHUNKED(true, 2);
                 else if (fast && d_tols) LRM_OCT_CHUNKED(true, 1);
                 else if (fast) LRM_OCT_CHUNKED(true, 0);
                 else LRM_OCT_CHUNKED(false, 0);
@@ -926,7 +1137,7 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
     }
     *n_out = count;
     if (ms) *ms = total_ms;
-    if (dbg) { fprintf(stderr, "apply_oct: %zu nodes, leaves extracted in %.2f ms\n", nodes.size(), ms_since(t_phase)); t_phase = now(); }
+    if (dbg) { fprintf(stderr, "apply_oct: %zu nodes, leaves extracted in %.2f ms; %llu (item, orientation) pairs went through the deferred queue\n", nodes.size(), ms_since(t_phase), deferred_total); t_phase = now(); }
     cleanup();
     if (dbg) fprintf(stderr, "apply_oct: device memory released in %.2f ms\n", ms_since(t_phase));
 #undef OCT_TRY

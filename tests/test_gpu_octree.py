@@ -8,15 +8,18 @@ from octree_oracle import apply_oct as oracle_apply_oct
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["strict", "fast", "fast_tol", "fast_tab"])
+@pytest.fixture(autouse=True, params=["strict", "fast", "fast_tol", "fast_tab", "fast_tab_inline"])
 def mode(request, lrm, monkeypatch):
     """strict: lrm_point.h verbatim; fast: the filtered code for every work item (LRM_OCT_TOL=0); fast_tol: the contract-tolerance
     evaluation first, the filtered code for its doubts and for vectors that end near a face of the child box (LRM_OCT_TOL=1: whatever
     the cloud's size; the library's default takes it from 3e5 footholds on), without plane tables (LRM_OCT_TAB=0); fast_tab: the same
-    through the plane tables of the (orientation, leg) pairs (the default).  All four must give the same leaves."""
+    through the plane tables of the (orientation, leg) pairs, the doubtful (item, orientation) pairs of levels with 256 children or
+    more queued for a second launch (the default); fast_tab_inline: the tables with the doubts redone in place (LRM_OCT_DEFER=0).
+    All five must give the same leaves."""
     lrm.set_mode(lrm.MODE_STRICT if request.param == "strict" else lrm.MODE_FAST)
-    monkeypatch.setenv("LRM_OCT_TOL", "1" if request.param in ("fast_tol", "fast_tab") else "0")
-    monkeypatch.setenv("LRM_OCT_TAB", "1" if request.param == "fast_tab" else "0")
+    monkeypatch.setenv("LRM_OCT_TOL", "1" if request.param in ("fast_tol", "fast_tab", "fast_tab_inline") else "0")
+    monkeypatch.setenv("LRM_OCT_TAB", "1" if request.param in ("fast_tab", "fast_tab_inline") else "0")
+    monkeypatch.setenv("LRM_OCT_DEFER", "0" if request.param == "fast_tab_inline" else "1")
     yield request.param
     lrm.set_mode(lrm.MODE_FAST)
 
@@ -256,6 +259,23 @@ def test_apply_oct_random_settings_three_traversals_agree(lrm, seed):
     for name, r in results.items():
         assert np.array_equal(got.view(np.uint32), r.view(np.uint32)), (name, len(got), len(r))
     print(f"seed {seed}: {n} footholds, half {half}, depth {st.max_depth}, {st.leg_count} legs, stability {st.leg_number_for_stab}: {len(got)} leaves")
+
+
+def test_deferred_queue_that_overflows_runs_the_level_again_inline(lrm, mode, monkeypatch):
+    """The queue of deferred (item, orientation) pairs is sized from the cloud; when it overflows the kernel raises a flag and the
+    host evaluates the level again with the doubts in place.  Forced here (64 records, every level deferred): the same leaves."""
+    if mode != "fast_tab":
+        pytest.skip("the deferred form only")
+    f = footholds(6000, seed=31)
+    dim = lrm.get_M2_leg(0.0)
+    st = settings(lrm, 400.0, 5, stab=3)
+    want, _ = lrm.apply_oct(f, dim, st)
+    monkeypatch.setenv("LRM_OCT_DEFER_FROM", "1")
+    every_level, _ = lrm.apply_oct(f, dim, st)
+    monkeypatch.setenv("LRM_OCT_DEFER_CAP", "64")
+    overflowed, _ = lrm.apply_oct(f, dim, st)
+    assert len(want) > 0
+    assert np.array_equal(want.view(np.uint32), every_level.view(np.uint32)) and np.array_equal(want.view(np.uint32), overflowed.view(np.uint32))
 
 
 def test_config5_share_of_one_gpu_with_an_oracle_sample(lrm, oracle, mode):
