@@ -152,6 +152,31 @@ def cpu_baseline(sample_points, leg):
     return out
 
 
+def config5_block(torch, lrm_amd, n=12_500_000, depth=6):
+    """BASELINE config 5 at ONE GPU's share outside the timed headline: the octree-culled positionability (lrm_apply_oct_dev) on
+    1.25e7 synthetic footholds of a 10 m x 10 m relief (the N = 8 share of the 1e8-point cloud), the reference's settings (root box
+    +-5000 mm, min box 100 mm, 27 orientations below 50 mm), 4 legs, stability 3, depth 6.  kernel_ms = the level kernels of the second
+    call (the first one also builds and caches the 108 plane tables)."""
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(-5000, 5000, (n, 2)).astype(np.float32)
+    z = (400 * np.sin(xy[:, 0] / 900) * np.cos(xy[:, 1] / 700) + 60 * np.sin(xy[:, 0] / 130) + rng.normal(0, 5, n) - 200).astype(np.float32)
+    t = torch.from_numpy(np.ascontiguousarray(np.column_stack([xy, z]).astype(np.float32).T)).cuda()
+    del xy, z
+    dim = lrm_amd.get_M2_leg(0.0)
+    st = lrm_amd.octree_default_settings()
+    st.max_depth = depth
+    st.leg_number_for_stab = 3
+    t0 = time.perf_counter()
+    leaves, ms_first = lrm_amd.device.apply_oct(t[0], t[1], t[2], dim, st)
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    leaves, ms = lrm_amd.device.apply_oct(t[0], t[1], t[2], dim, st)
+    wall = time.perf_counter() - t0
+    return {"workload": f"apply_oct, {n} device-resident footholds on a 10 m x 10 m relief, depth {depth}, 4 legs, stability 3 (one GPU's share of BASELINE config 5)",
+            "data": "synthetic", "kernel_ms": ms, "wall_ms": wall * 1e3, "first_call_wall_ms": first * 1e3, "leaves": int(len(leaves)),
+            "parity": "pinned by composition only (tests/test_gpu_octree.py against tests/octree_oracle.py): the reference's call site is dead code"}
+
+
 def config3_block(torch, lrm_amd):
     """BASELINE config 3 outside the timed headline: 6-leg positionability, one launch of lrm_reach_any_dev on the
     reference's own terrain and near-ground body lattice (tests/golden/terrain_ground.npz) in Morton order."""
@@ -661,6 +686,7 @@ def main():
             lrm_amd.set_mode(modes[args.mode])
             extra.update(cache_and_scaling_block(torch, lrm_amd, leg, cloud, mask, field, time_kernel))
             configs["c3_positionability"] = config3_block(torch, lrm_amd)
+            configs["c5_octree_share"] = config5_block(torch, lrm_amd)
     if world > 1:
         dist.barrier()
 
