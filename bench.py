@@ -615,9 +615,15 @@ def main():
         tol_check["mode"] = args.mode
 
     def time_kernel(fn, reps=100):
-        for _ in range(20):
-            fn()
-        torch.cuda.synchronize()
+        # warm-up by TIME: the checks between the timed sections leave the GPU idle for seconds, and it needs some 50 ms of load to be
+        # back at its steady clocks (20 launches of a 0.1 ms step were not: the side modes read 6 % slow against tools/bench_modes.py)
+        t_warm = time.perf_counter()
+        while True:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            if time.perf_counter() - t_warm >= 0.08:
+                break
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(reps):

@@ -19,6 +19,14 @@ def t(f, reps=500):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
 only = sys.argv[1] if len(sys.argv) > 1 else None
+if only == "bits":
+    for mode in ("MODE_TOL_REL", "MODE_TOL"):
+        lrm.set_mode(getattr(lrm, mode))
+        for rep in range(3):
+            print(mode, "mask+bits %.5f" % t(lambda: lrm.device.reach_dist(x, y, z, leg, None, mask=mask, out=field, bits=bits)),
+                  "mask only %.5f" % t(lambda: lrm.device.reach_dist(x, y, z, leg, None, mask=mask, out=field)),
+                  "bits only %.5f" % t(lambda: lrm.device.reach_dist(x, y, z, leg, None, out=field, bits=bits)), flush=True)
+    sys.exit(0)
 if only:
     lrm.set_mode(lrm.MODE_TOL_REL)
     print(only, t({"novalid": lambda: lrm.device.dist(x, y, z, leg, out=field, want_valid=False), "valid": lambda: lrm.device.dist(x, y, z, leg, out=field, valid=valid)}[only]))
