@@ -19,6 +19,10 @@ def t(f, reps=500):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
 only = sys.argv[1] if len(sys.argv) > 1 else None
+if only in ("maskbits", "maskonly"):
+    lrm.set_mode(lrm.MODE_TOL_REL)
+    print(only, t((lambda: lrm.device.reach_dist(x, y, z, leg, None, mask=mask, out=field, bits=bits)) if only == "maskbits" else (lambda: lrm.device.reach_dist(x, y, z, leg, None, mask=mask, out=field))))
+    sys.exit(0)
 if only == "bits":
     for mode in ("MODE_TOL_REL", "MODE_TOL"):
         lrm.set_mode(getattr(lrm, mode))
