@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kOctBlock, kDefer ? LRM_OCT_DEFER_MIN_WAVES : LRM_O
     const OctChild* __restrict__ children, int n_children, const float* __restrict__ fx,
     const float* __restrict__ fy, const float* __restrict__ fz, size_t nf, const float* __restrict__ boxes, size_t ntiles,
     const LrmCompiledLeg* __restrict__ legs, const LrmTolLeg* __restrict__ tols, const uint8_t* const* __restrict__ tabs, const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float reach_len,
-    float convex_r2, uint32_t* __restrict__ flags /* zeroed by the host */, uint32_t splits, const OctDeferQueue Q /* kDefer */) {
+    float convex_r2, uint32_t* __restrict__ flags /* zeroed by the host */, uint32_t splits, uint32_t tpr /* tiles per round, <= kOctBlock */, const OctDeferQueue Q /* kDefer */) {
     static_assert(!kDefer || (kFast && kTol == 2), "the deferred form is the table form");
     __shared__ uint32_t s_flags, s_ntiles, s_nchunks;
     __shared__ uint32_t s_defer[kDefer ? (kOctBlock / 64) * kOctDeferSeg * 3 : 1];
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kOctBlock, kDefer ? LRM_OCT_DEFER_MIN_WAVES : LRM_O
         const float hd = sqrtf(h2 + fmaxf(ch.margin, 0.f)) * 1.0001f + 0.01f;
         if (threadIdx.x == 0) s_flags = 0;
         __syncthreads();
-        for (size_t tile0 = (size_t)sp * kOctBlock; tile0 < ntiles; tile0 += (size_t)splits * kOctBlock) {
+        for (size_t tile0 = (size_t)sp * tpr; tile0 < ntiles; tile0 += (size_t)splits * tpr) {
             if (threadIdx.x == 0) {
                 s_ntiles = 0;
                 s_nchunks = 0;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kOctBlock, kDefer ? LRM_OCT_DEFER_MIN_WAVES : LRM_O
             __syncthreads();
             if (s_flags == 7u) break; // nothing left to learn (block-uniform: read after the barrier)
             const size_t t = tile0 + threadIdx.x;
-            if (t < ntiles && box_meets(boxes + t * 6, ch.c, H)) s_tiles[atomicAdd(&s_ntiles, 1u)] = (uint32_t)t;
+            if (threadIdx.x < tpr && t < ntiles && box_meets(boxes + t * 6, ch.c, H)) s_tiles[atomicAdd(&s_ntiles, 1u)] = (uint32_t)t;
             __syncthreads();
             const uint32_t nt = s_ntiles;
             for (uint32_t k = threadIdx.x; k < nt * 16u; k += kOctBlock) {
@@ -478,6 +478,9 @@ __global__ __launch_bounds__(kOctBlock) void oct_deferred_kernel( // (every lane
     const OctChild* __restrict__ children, const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ fz,
     const LrmCompiledLeg* __restrict__ legs, const float4* __restrict__ spheres, int leg_count, int legs_for_stab, float convex_r2,
     uint32_t* __restrict__ flags, const OctDeferQueue Q) {
+    // A queue that overflowed has holes (a flush that did not fit wrote nothing, later ones may have): nothing of it is read -- the
+    // host sees the flag and runs the level again with the doubts in place.
+    if (Q.count[1] != 0u) return;
     const uint32_t n = Q.count[0] < Q.cap ? Q.count[0] : Q.cap;
     for (uint32_t k = blockIdx.x * kOctBlock + threadIdx.x; k < n; k += gridDim.x * kOctBlock) {
         const uint32_t child = Q.rec[3u * k], f = Q.rec[3u * k + 1u];
@@ -1014,15 +1017,23 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
             const bool brute = getenv("LRM_OCT_BRUTE") && getenv("LRM_OCT_BRUTE")[0] == '1' && nc <= 65535;
             size_t chunked_from = (size_t)kOctChunkedFrom;
             if (const char* e = getenv("LRM_OCT_CHUNKED_FROM")) chunked_from = (size_t)atol(e); // experiments
-            if (nc >= chunked_from && !brute) {
+            // (the first level's 8 huge children too when the cloud has enough tiles to spread them over the chip: 6.4 -> 4.0 ms at 1.25e7 footholds)
+            if ((nc >= chunked_from || (!getenv("LRM_OCT_CHUNKED_FROM") && nc * ((ntiles + 31) / 32) >= 2048)) && !brute) {
                 // many small children: one workgroup per child, only the footholds of nearby chunks
                 // workgroups per child: at least ~4096 workgroups in flight, at most one per round of 256 tiles
-                size_t splits = nc >= 4096 ? 1 : (4096 + nc - 1) / nc;
-                splits = std::min(splits, std::max<size_t>(1, (ntiles + kOctBlock - 1) / kOctBlock));
-                splits = std::min<size_t>(splits, 64);
+                // (levels of few, huge children: rounds of fewer tiles, so that more workgroups share a child and look at its flags more often)
+                // config-5 share, levels of 64 / 256 / 976 / 4112 children: 11.6 / 9.2 / 9.9 / 14.3 ms with rounds of 256 tiles and 4096
+                // workgroups -> 5.3 / 6.1 / 8.4 / 13.4 ms (profiles/r04_octree.txt); the deepest level (15 856 children) is best left alone
+                size_t tpr = nc < 2048 ? 32 : (nc < 8192 ? 128 : kOctBlock);
+                if (const char* e = getenv("LRM_OCT_TPR")) tpr = std::min<size_t>(std::max<size_t>((size_t)atol(e), 1), kOctBlock);
+                size_t want_wgs = nc < 2048 ? 32768 : (nc < 8192 ? 8192 : 4096);
+                if (const char* e = getenv("LRM_OCT_WGS")) want_wgs = (size_t)atol(e);
+                size_t splits = nc >= want_wgs ? 1 : (want_wgs + nc - 1) / nc;
+                splits = std::min(splits, std::max<size_t>(1, (ntiles + tpr - 1) / tpr));
+                splits = std::min<size_t>(splits, 256);
                 const dim3 grid((unsigned)std::min<size_t>(nc * splits, (size_t)256 * 64));
 #define LRM_OCT_CHUNKED(FAST, TOL) hipLaunchKernelGGL((oct_validity_chunked_kernel<FAST, TOL>), grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf, \
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_tabs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits, OctDeferQueue{nullptr, nullptr, 0u})
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_tabs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits, (uint32_t)tpr, OctDeferQueue{nullptr, nullptr, 0u})
                 bool deferred_done = false;
                 // the table form with its doubts queued for a second launch (see oct_item_flags_defer) -- from 256 children on: the few huge
                 // children of the first levels saturate their flags early, and later when some of their items wait in the queue
@@ -1031,7 +1042,7 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
                     const OctDeferQueue Q{d_defer, d_defer_count, (uint32_t)oct_defer_cap(nf)};
                     OCT_TRY(hipMemsetAsync(d_defer_count, 0, 32 * sizeof(uint32_t), nullptr), "hipMemsetAsync");
                     hipLaunchKernelGGL((oct_validity_chunked_kernel<true, 2, true>), grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
-                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_tabs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits, Q);
+                                       d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_tabs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits, (uint32_t)tpr, Q);
                     OCT_TRY(hipGetLastError(), "Kernel launch");
                     hipLaunchKernelGGL(oct_deferred_kernel, dim3(2048), dim3(kOctBlock), 0, nullptr, d_children, d_f, d_f + nf, d_f + 2 * nf, d_legs, d_spheres,
                                        st.leg_count, st.leg_number_for_stab, cr2, d_flags, Q);
