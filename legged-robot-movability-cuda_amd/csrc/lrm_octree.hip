@@ -261,7 +261,6 @@ __device__ __forceinline__ uint32_t oct_item_flags_defer(const OctChild& ch, boo
                     }
 #if defined(LRM_OCT_COUNT)
                     if ((dbt & 0xffffu) != 0u) why = 2u; else if (near_face) why = 3u;
-                    if ((dbt & 0xffffu) != 0u && (threadIdx.x & 63u) < 64u) atomicAdd(Q.count + 8 + (31 - __builtin_clz(dbt & 0xffffu)), 1u);
 #endif
                     if ((dbt & 0xffffu) != 0u || near_face) dfr = true;
                     else {
@@ -910,7 +909,7 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
                 const char* ed = getenv("LRM_OCT_DEFER"); // LRM_OCT_DEFER=0: the doubts of the table form inline (A/B runs and tests)
                 if (!ed || ed[0] != '0') {
                     OCT_TRY(hipMalloc(reinterpret_cast<void**>(&d_defer), oct_defer_cap(nf) * 3 * sizeof(uint32_t)), "hipMalloc deferred pairs");
-                    OCT_TRY(hipMalloc(reinterpret_cast<void**>(&d_defer_count), 32 * sizeof(uint32_t)), "hipMalloc deferred count");
+                    OCT_TRY(hipMalloc(reinterpret_cast<void**>(&d_defer_count), 8 * sizeof(uint32_t)), "hipMalloc deferred count");
                 }
             }
         }
@@ -1040,19 +1039,17 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
                 const size_t defer_from = getenv("LRM_OCT_DEFER_FROM") ? (size_t)atol(getenv("LRM_OCT_DEFER_FROM")) : (size_t)256;
                 if (fast && d_tabs && d_defer && nc >= defer_from) {
                     const OctDeferQueue Q{d_defer, d_defer_count, (uint32_t)oct_defer_cap(nf)};
-                    OCT_TRY(hipMemsetAsync(d_defer_count, 0, 32 * sizeof(uint32_t), nullptr), "hipMemsetAsync");
+                    OCT_TRY(hipMemsetAsync(d_defer_count, 0, 8 * sizeof(uint32_t), nullptr), "hipMemsetAsync");
                     hipLaunchKernelGGL((oct_validity_chunked_kernel<true, 2, true>), grid, dim3(kOctBlock), 0, nullptr, d_children, (int)nc, d_f, d_f + nf,
                                        d_f + 2 * nf, nf, d_boxes, ntiles, d_legs, d_tols, d_tabs, d_spheres, st.leg_count, st.leg_number_for_stab, reach_len, cr2, d_flags, (uint32_t)splits, (uint32_t)tpr, Q);
                     OCT_TRY(hipGetLastError(), "Kernel launch");
                     hipLaunchKernelGGL(oct_deferred_kernel, dim3(2048), dim3(kOctBlock), 0, nullptr, d_children, d_f, d_f + nf, d_f + 2 * nf, d_legs, d_spheres,
                                        st.leg_count, st.leg_number_for_stab, cr2, d_flags, Q);
                     OCT_TRY(hipGetLastError(), "Kernel launch");
-                    uint32_t qc[32] = {0};
+                    uint32_t qc[8] = {0};
                     OCT_TRY(hipMemcpy(qc, d_defer_count, sizeof qc, hipMemcpyDeviceToHost), "hipMemcpy queue count");
 #if defined(LRM_OCT_COUNT)
-                    fprintf(stderr, "apply_oct: level %d: %u pairs evaluated, %u queued (overflow %u): no table %u, doubt %u, near face %u; doubt bits:", depth, qc[2], qc[0], qc[1], qc[3], qc[4], qc[5]);
-                    for (int b = 0; b < 16; b++) fprintf(stderr, " %u", qc[8 + b]);
-                    fprintf(stderr, "\n");
+                    fprintf(stderr, "apply_oct: level %d: %u pairs evaluated, %u queued (overflow %u): no table %u, doubt %u, near face %u\n", depth, qc[2], qc[0], qc[1], qc[3], qc[4], qc[5]);
 #endif
                     deferred_total += qc[0];
                     if (qc[1] == 0) deferred_done = true;
