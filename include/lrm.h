@@ -277,7 +277,9 @@ typedef struct LrmOctreeSettings {
 void lrm_octree_default_settings(LrmOctreeSettings* out);
 /* footholds: AoS float3 (Array<float3> input of apply_oct); centers_out: room for `capacity` float3;
  * *n_out = number of valid leaves (if > capacity the call fails with LRM_EINVAL and *n_out tells the
- * size to retry with); settings = NULL -> defaults; *ms = kernel time. */
+ * size to retry with); settings = NULL -> defaults; *ms = kernel time.
+ * From 3e5 footholds on (LRM_MODE_FAST) the work items' decisions come from the plane tables of the (leg, orientation) pairs, built
+ * on the device on the first call that meets a pair (~0.4 ms each) and kept for the process; the tree is the same. */
 int lrm_apply_oct(const float* footholds_aos, size_t n, const LrmLegDimensions* dim,
                   const LrmOctreeSettings* settings, float* centers_out, size_t capacity, size_t* n_out,
                   float* ms);
