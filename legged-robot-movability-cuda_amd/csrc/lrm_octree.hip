@@ -875,11 +875,11 @@ static int apply_oct_impl(const float* footholds /* host AoS, or null */, const 
                     key[14] = q.x; key[15] = q.y; key[16] = q.z; key[17] = q.w;
                     auto it = cache.find(key);
                     if (it == cache.end()) {
-                        if (cache.size() >= 1024) {
-                            for (auto& kv : cache)
-                                for (auto& dt : kv.second.tab_dev)
-                                    if (dt.second) (void)hipFree(dt.second); // (no launch of an earlier call is still running: every call ends with a synchronous copy)
-                            cache.clear();
+                        // A full cache takes no new entry (and frees nothing: another thread's call may be running on its tables): this
+                        // pair goes without a table -- its items through the filtered code (4096 pairs: a thousand robots' worth).
+                        if (cache.size() >= 4096) {
+                            lrm_compile_tol(legs[(size_t)a * st.leg_count + l], &tols[(size_t)a * st.leg_count + l]);
+                            continue;
                         }
                         Entry en;
                         lrm_compile_tol(legs[(size_t)a * st.leg_count + l], &en.tl);
