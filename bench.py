@@ -17,7 +17,7 @@ bit words + 3-component distance field) over a synthetic cloud that is already r
           overlapping the next step's kernel).  Strong scaling: the total work is fixed.
 
 The headline runs in LRM_MODE_TOL_REL, the literal text of BASELINE.json: reach mask bit-exact and |d - d_ref| <= 1e-5 |d_ref|
-for EVERY distance vector (vectors shorter than max(17 mm, 2000 decision bands) come from the table-guided bit-exact chain of
+for EVERY distance vector (vectors shorter than max(19 mm, 2250 decision bands) come from the table-guided bit-exact chain of
 csrc/lrm_point_xtab.h, all others from the tolerance arithmetic).  The line carries the error statistics of the very output
 it timed ("tolerance_check").  Timed next to it and reported under "modes" with their own roofline fractions:
 LRM_MODE_FAST (every float of the distance field identical to the reference's host path: tolerance 0; since round 4 the
@@ -750,7 +750,7 @@ def main():
                 "mode_contract": {"tol": "reach mask bit-exact; distance within 1e-5 of max(|d|, (|p| + body)/8): a FLOORED reading of "
                                          "BASELINE's '1e-5 relative' (include/lrm.h; literal relative error in tolerance_check)",
                                   "tol_rel": "reach mask bit-exact; |d - d_ref| <= 1e-5 |d_ref| for every vector (BASELINE's text without a floor: vectors "
-                                             "shorter than 17 mm come from the bit-exact code)",
+                                             "shorter than 19 mm come from the bit-exact code)",
                                   "fast": "mask and every float of the distance field bit-identical to the reference's host path (table-guided kernel)",
                                   "strict": "as fast, reference operation order"}[args.mode],
                 "exchange": "none" if world == 1 else f"{'RCCL' if backend == 'nccl' else backend} all-gather of the "

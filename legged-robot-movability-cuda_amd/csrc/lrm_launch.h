@@ -23,10 +23,10 @@ hipError_t lrm_launch_dist_soa(int op, const float* x, const float* y, const flo
 // flags of the tolerance-mode launches (bits 0 and 1 are LRM_TOL_SELFTEST's)
 #define LRM_TOLF_SHORT 4u     // LRM_MODE_TOL_REL: every vector shorter than LRM_TOL_REL_MM is queued for the bit-exact fix-up
 #ifndef LRM_TOL_REL_MM
-#define LRM_TOL_REL_MM 17.0f  // the literal bound |d - d_ref| <= 1e-5 |d_ref| is asserted from 16 mm on; 1 mm for the vector's own error
+#define LRM_TOL_REL_MM 19.0f  // the literal bound |d - d_ref| <= 1e-5 |d_ref| is asserted from 16 mm on (17 mm until the third campaign of round 4 found 7.6e-6 at 17.55 mm: the threshold and the band count below went up by an eighth, 0.9 us per 1e7 points)
 #endif
 #ifndef LRM_TOL_REL_BANDS
-#define LRM_TOL_REL_BANDS 2000.0f // ... and from 2000 decision bands on (30 mm at |p|_1 + body = 1 m): the error grows with the coordinates
+#define LRM_TOL_REL_BANDS 2250.0f // ... and from 2250 decision bands on (34 mm at |p|_1 + body = 1 m): the error grows with the coordinates
 #endif
 size_t lrm_tol_queue_words(size_t n);
 hipError_t lrm_launch_dist_tol_aos(int op, const float* xyz, size_t n, const LrmCompiledLeg& L, const LrmTolLeg& TL, uint8_t* mask,
