@@ -58,13 +58,6 @@ struct OctChild {          // one child box of the level being evaluated
     int32_t pad;
 };
 
-// A child's three flags are ORs over its work items, and what the tree takes from them is: validity = reach, leaf = leaf,
-// onEdge = edge and not leaf (apply_oct_impl; several_leg_octree.cu:134-150).  An item that sets `leaf` sets `reach` with it
-// (leaf = reach and not edge), so from the first such item on the child's node is decided whatever the remaining items say:
-// a valid leaf.  (Until round 4 a child left only with all three flags set: the children INSIDE the positionable region, which
-// never see an edge item, walked every foothold of their elongated box.)
-__device__ __forceinline__ bool oct_settled(uint32_t flags) { return (flags & 2u) != 0u; }
-
 // isInBox, octree_util.cu.h:153-159 (note the asymmetric comparisons)
 __device__ __forceinline__ bool in_box(LrmVec3 v, float hx, float hy, float hz) {
     hx = fabsf(hx); hy = fabsf(hy); hz = fabsf(hz);
@@ -328,7 +321,7 @@ __global__ __launch_bounds__(kOctBlock, LRM_OCT_MIN_WAVES) void oct_validity_ker
         // The three flags are ORs: once all are set for this child, nothing is left to learn.  The huge boxes of
         // the first levels see every foothold and saturate after a few hundred of them -- without this exit a level
         // costs 45 ms per 1e6 footholds.  (Wave-uniform: every lane reads the same word.)
-        if (oct_settled(*reinterpret_cast<volatile uint32_t*>(&flags[blockIdx.y]))) break;
+        if (*reinterpret_cast<volatile uint32_t*>(&flags[blockIdx.y]) == 7u) break;
         uint32_t wave_bits = mine;
         for (int off = 32; off > 0; off >>= 1) wave_bits |= __shfl_xor(wave_bits, off);
         if ((threadIdx.x & 63) == 0 && (wave_bits & ~published)) atomicOr(&flags[blockIdx.y], wave_bits);
@@ -440,7 +433,7 @@ __global__ __launch_bounds__(kOctBlock, kDefer ? LRM_OCT_DEFER_MIN_WAVES : LRM_O
                 }
             }
             __syncthreads();
-            if (oct_settled(s_flags)) break; // nothing left to learn (block-uniform: read after the barrier)
+            if (s_flags == 7u) break; // nothing left to learn (block-uniform: read after the barrier)
             const size_t t = tile0 + threadIdx.x;
             if (threadIdx.x < tpr && t < ntiles && box_meets(boxes + t * 6, ch.c, H)) s_tiles[atomicAdd(&s_ntiles, 1u)] = (uint32_t)t;
             __syncthreads();
@@ -452,7 +445,7 @@ __global__ __launch_bounds__(kOctBlock, kDefer ? LRM_OCT_DEFER_MIN_WAVES : LRM_O
             __syncthreads();
             const uint32_t nchunks = s_nchunks;
             for (uint32_t k = threadIdx.x >> 6; k < nchunks; k += kOctBlock / 64) { // a wave per surviving chunk
-                if (oct_settled(*reinterpret_cast<volatile uint32_t*>(&s_flags))) break;
+                if (*reinterpret_cast<volatile uint32_t*>(&s_flags) == 7u) break;
                 const size_t f = (size_t)s_chunks[k] * 64 + (threadIdx.x & 63);
                 uint32_t mine = 0;
                 if (kDefer) { // every lane of the wave together (ballots inside)
@@ -491,7 +484,7 @@ __global__ __launch_bounds__(kOctBlock) void oct_deferred_kernel( // (every lane
     for (uint32_t k = blockIdx.x * kOctBlock + threadIdx.x; k < n; k += gridDim.x * kOctBlock) {
         const uint32_t child = Q.rec[3u * k], f = Q.rec[3u * k + 1u];
         const int a = (int)Q.rec[3u * k + 2u];
-        if (oct_settled(*reinterpret_cast<volatile uint32_t*>(&flags[child]))) continue;
+        if (*reinterpret_cast<volatile uint32_t*>(&flags[child]) == 7u) continue;
         const OctChild ch = children[child];
         const LrmVec3 vect{fx[f] - ch.c[0], fy[f] - ch.c[1], fz[f] - ch.c[2]};
         const float h2 = ch.h[0] * ch.h[0] + ch.h[1] * ch.h[1] + ch.h[2] * ch.h[2];
